@@ -1,0 +1,74 @@
+// Internal helpers shared by the HIP translation units of libmv3d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <functional>
+#include "../../include/mv3d_hip.h"
+
+namespace mv3d {
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+bool recording();
+void record(std::function<int(hipStream_t)> fn);
+
+// Launch now, or append to the plan being recorded on this thread (mv3d_plan_begin).
+template <class F>
+inline int dispatch(void* stream, F fn) {
+    if (recording()) { record(std::function<int(hipStream_t)>(fn)); return MV3D_OK; }
+    return fn(reinterpret_cast<hipStream_t>(stream));
+}
+
+inline int launched(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MV3D_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return MV3D_OK;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// TF 'SAME' padding: pad_before = total/2
+static inline void same_pad(int size, int k, int s, int* out, int* before) {
+    int o = (size + s - 1) / s;
+    int total = (o - 1) * s + k - size;
+    if (total < 0) total = 0;
+    *out = o;
+    *before = total / 2;
+}
+
+// ---- device-side activation helpers -------------------------------------------------------
+// Forward: f1*x + f2*|x| exactly as tf_utils.py:25-33 writes it (two products, one sum).
+// RELU stores -0.0f for x < 0 so the backward pass can tell x < 0 (slope 0) from x == 0
+// (slope 0.5, TF's sign(0) = 0); -0.0f is arithmetically identical to +0.0f downstream.
+__device__ __forceinline__ float act_apply(float x, int act, float leak) {
+    if (act == MV3D_ACT_LRELU) {
+        float f1 = 0.5f * (1.0f + leak), f2 = 0.5f * (1.0f - leak);
+        return __fadd_rn(__fmul_rn(f1, x), __fmul_rn(f2, fabsf(x)));
+    }
+    if (act == MV3D_ACT_RELU) {
+        float y = __fadd_rn(__fmul_rn(0.5f, x), __fmul_rn(0.5f, fabsf(x)));
+        return x < 0.0f ? -0.0f : y;
+    }
+    if (act == MV3D_ACT_TANH) return tanhf(x);
+    return x;
+}
+
+// Derivative of the activation evaluated from its OUTPUT y.
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float leak) {
+    if (act == MV3D_ACT_LRELU) {
+        float f1 = 0.5f * (1.0f + leak), f2 = 0.5f * (1.0f - leak);
+        float s = (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f);   // sign(out) == sign(pre)
+        return f1 + f2 * s;
+    }
+    if (act == MV3D_ACT_RELU) {
+        if (y > 0.0f) return 1.0f;
+        return (__float_as_uint(y) >> 31) ? 0.0f : 0.5f;               // -0.0 marks pre < 0
+    }
+    if (act == MV3D_ACT_TANH) return 1.0f - y * y;
+    return 1.0f;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace mv3d

@@ -1,0 +1,738 @@
+// conv2d / conv2d_transpose forward + backward for gfx950 as three implicit-GEMM primitives
+// over (image side [N,H,W,C], feature side [N,Ho,Wo,K], filter [kh,kw,C,K]):
+//
+//   img2feat : feat[n,ho,wo,k]  = sum img[n,ho*s+p-pt,wo*s+q-pl,c] * f[p,q,c,k]   conv fwd, deconv dgrad
+//   feat2img : img[n,u,v,c]     = sum feat[n,i,j,k] * f[u-i*s+pt, v-j*s+pl, c,k]  conv dgrad, deconv fwd
+//   filtgrad : df[p,q,c,k]      = sum img[n,ho*s+p-pt,...,c] * feat[n,ho,wo,k]    conv/deconv wgrad
+//
+// TF-1.3 semantics being restated: tf.nn.conv2d SAME (tf_utils.py:81) and
+// tf.nn.conv2d_transpose == Conv2DBackpropInput (tf_utils.py:96); SURVEY Appendix A.1/A.2.
+//
+// img2feat/feat2img share ONE kernel (igemm_kernel): the output pixels of a launch are split into
+// stride phases; inside a phase every output pixel uses the same tap list
+// (dh, dw, filter tap), and the input pixel is (oh'*sa + dh, ow'*sa + dw).  A strided transposed
+// conv therefore becomes s*s dense sub-convolutions with no multiplications by structural zeros.
+// Tiles are staged global -> registers -> LDS (next tile's loads in flight during the MFMAs) and
+// multiplied with v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
+#include "common.h"
+#include <algorithm>
+
+namespace mv3d {
+
+struct IgemmTap { int8_t dh, dw; int16_t widx; };
+
+struct IgemmParams {
+    const float* A;      // input activations
+    const float* Wt;     // filter [kh*kw][C][K]
+    float* Out;          // output activations
+    float* Part;         // split-K partials [ksplit][N*Hc*Wc][Cc] (ksplit > 1)
+    int N, Ha, Wa, Ca, a_ld;
+    int Hc, Wc, Cc, c_ld;
+    int sa_h, sa_w;      // input coordinate multiplier
+    int so_h, so_w;      // output phase stride
+    int Hp[2], Wp[2];    // per-phase output sub-grid
+    int tap_begin[5];
+    IgemmTap taps[36];
+    int fold;            // 1: a tap covers kw*Ca contiguous elements of a dense NHWC row (small Ca)
+    int Ka;              // reduction extent per tap
+    int w_tap_stride, w_ks, w_ns;
+    int ksplit;
+    // epilogue
+    const float* bias; int act; float leak;
+    int gact; float gleak; const float* gref; int g_ld;
+};
+
+__device__ __forceinline__ float epilogue_value(const IgemmParams& p, float v, int64_t pix, int col) {
+    if (p.bias) v += p.bias[col];
+    v = act_apply(v, p.act, p.leak);
+    if (p.gact != MV3D_ACT_NONE) v *= act_grad_from_out(p.gref[pix * p.g_ld + col], p.gact, p.gleak);
+    return v;
+}
+
+// WM waves along M (4/WM along N); each wave owns a (32*MT) x (32*NT) output tile.
+template <int WM, int MT, int NT, bool VEC, bool BKMAJOR>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    constexpr int BK = 32;
+    constexpr int WN = 4 / WM;
+    constexpr int BM = WM * 32 * MT;
+    constexpr int BN = WN * 32 * NT;
+    constexpr int LDA = BK + 1;
+    constexpr int LDB = BN + 1;
+    constexpr int A_PASSES = VEC ? BM / 32 : BM / 8;
+    constexpr int B_LOADS = BK * BN / 256;
+
+    __shared__ float As[BM * LDA];
+    __shared__ float Bs[BK * LDB];
+    __shared__ int s_rowbase[BM], s_ih0[BM], s_iw0[BM], s_outpix[BM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int ks = blockIdx.z % p.ksplit;
+    const int ph = blockIdx.z / p.ksplit;
+    const int phh = ph / p.so_w, phw = ph % p.so_w;
+    const int Hp = p.Hp[phh], Wp = p.Wp[phw];
+    const int Mp = p.N * Hp * Wp;
+    const int m0 = blockIdx.x * BM;
+    if (m0 >= Mp) return;
+    const int n0 = blockIdx.y * BN;
+
+    for (int r = tid; r < BM; r += 256) {
+        int m = m0 + r;
+        if (m < Mp) {
+            int n = m / (Hp * Wp);
+            int rem = m - n * (Hp * Wp);
+            int ohp = rem / Wp, owp = rem - ohp * Wp;
+            s_rowbase[r] = n * p.Ha * p.Wa;
+            s_ih0[r] = ohp * p.sa_h;
+            s_iw0[r] = owp * p.sa_w;
+            s_outpix[r] = (n * p.Hc + ohp * p.so_h + phh) * p.Wc + owp * p.so_w + phw;
+        } else {
+            s_rowbase[r] = 0; s_ih0[r] = -(1 << 28); s_iw0[r] = 0; s_outpix[r] = -1;
+        }
+    }
+    __syncthreads();
+
+    const int tap0 = p.tap_begin[ph];
+    const int ntap = p.tap_begin[ph + 1] - tap0;
+    const int kchunks = (p.Ka + BK - 1) / BK;
+    const int iters = ntap * kchunks;
+    const int it_begin = (int)((int64_t)iters * ks / p.ksplit);
+    const int it_end = (int)((int64_t)iters * (ks + 1) / p.ksplit);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    float4 ra4[VEC ? A_PASSES : 1];
+    float ra1[VEC ? 1 : A_PASSES];
+    float rb[B_LOADS];
+
+    auto load_tile = [&](int it) {
+        const int t = it / kchunks;
+        const int c0 = (it - t * kchunks) * BK;
+        const IgemmTap tap = p.taps[tap0 + t];
+        if constexpr (VEC) {
+            const int c = c0 + (tid & 7) * 4;
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const int r = ps * 32 + (tid >> 3);
+                const int ih = s_ih0[r] + tap.dh, iw = s_iw0[r] + tap.dw;
+                const bool ok = (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa && c < p.Ka;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v = *reinterpret_cast<const float4*>(p.A + (int64_t)(s_rowbase[r] + ih * p.Wa + iw) * p.a_ld + c);
+                ra4[ps] = v;
+            }
+        } else {
+            const int e = c0 + (tid & 31);
+            const int q = p.fold ? e / p.Ca : 0;
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                const int r = ps * 8 + (tid >> 5);
+                const int ih = s_ih0[r] + tap.dh, iw0 = s_iw0[r] + tap.dw;
+                const bool ok = (unsigned)ih < (unsigned)p.Ha && (unsigned)(iw0 + q) < (unsigned)p.Wa && e < p.Ka;
+                float v = 0.f;
+                if (ok) v = p.A[(int64_t)(s_rowbase[r] + ih * p.Wa + iw0) * p.a_ld + e];
+                ra1[ps] = v;
+            }
+        }
+        const float* wt = p.Wt + (int64_t)tap.widx * p.w_tap_stride;
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            int kk, nn;
+            if constexpr (BKMAJOR) { nn = tid % BN; kk = tid / BN + (256 / BN) * j; }
+            else { kk = tid & 31; nn = (tid >> 5) + 8 * j; }
+            const bool ok = (c0 + kk) < p.Ka && (n0 + nn) < p.Cc;
+            rb[j] = ok ? wt[(int64_t)(c0 + kk) * p.w_ks + (int64_t)(n0 + nn) * p.w_ns] : 0.f;
+        }
+    };
+
+    auto store_tile = [&]() {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) {
+                float* d = &As[(ps * 32 + (tid >> 3)) * LDA + (tid & 7) * 4];
+                d[0] = ra4[ps].x; d[1] = ra4[ps].y; d[2] = ra4[ps].z; d[3] = ra4[ps].w;
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < A_PASSES; ++ps) As[(ps * 8 + (tid >> 5)) * LDA + (tid & 31)] = ra1[ps];
+        }
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            int kk, nn;
+            if constexpr (BKMAJOR) { nn = tid % BN; kk = tid / BN + (256 / BN) * j; }
+            else { kk = tid & 31; nn = (tid >> 5) + 8 * j; }
+            Bs[kk * LDB + nn] = rb[j];
+        }
+    };
+
+    if (it_begin < it_end) load_tile(it_begin);
+    for (int it = it_begin; it < it_end; ++it) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (it + 1 < it_end) load_tile(it + 1);
+        const float* a_base = &As[(wm * 32 * MT + li) * LDA + lh];
+        const float* b_base = &Bs[lh * LDB + wn * 32 * NT + li];
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int x = 0; x < MT; ++x) a[x] = a_base[x * 32 * LDA + 2 * kp];
+#pragma unroll
+            for (int y = 0; y < NT; ++y) b[y] = b_base[2 * kp * LDB + y * 32];
+#pragma unroll
+            for (int x = 0; x < MT; ++x)
+#pragma unroll
+                for (int y = 0; y < NT; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int64_t npix_total = (int64_t)p.N * p.Hc * p.Wc;
+#pragma unroll
+    for (int x = 0; x < MT; ++x)
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+            const int col = n0 + wn * 32 * NT + y * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 * MT + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int pix = s_outpix[row];
+                if (pix >= 0 && col < p.Cc) {
+                    if (p.ksplit > 1) p.Part[((int64_t)ks * npix_total + pix) * p.Cc + col] = acc[x][y][r];
+                    else p.Out[(int64_t)pix * p.c_ld + col] = epilogue_value(p, acc[x][y][r], pix, col);
+                }
+            }
+        }
+}
+
+// split-K tail: sum the partial slabs, apply the epilogue, store with the output's pixel stride
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmParams p) {
+    const int64_t npix = (int64_t)p.N * p.Hc * p.Wc;
+    const int64_t total = npix * p.Cc;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t pix = idx / p.Cc;
+        const int col = (int)(idx - pix * p.Cc);
+        float s = 0.f;
+        for (int k = 0; k < p.ksplit; ++k) s += p.Part[(int64_t)k * total + idx];
+        p.Out[pix * p.c_ld + col] = epilogue_value(p, s, pix, col);
+    }
+}
+
+// feat2img with a thin image side (C <= 4: flow field, rgb / depth / mask heads): one thread per
+// output pixel on the VALU, the phase's filter taps staged once per block in LDS.  These layers are
+// HBM/L2-bound (AI ~ 40 flop/B): padding 2 channels to a 32-wide MFMA tile would multiply the work by 16.
+template <int CC>
+__global__ __launch_bounds__(256) void thin_feat2img_kernel(const IgemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];      // [ntap][CC][Ka]
+    const int ph = blockIdx.z;
+    const int phh = ph / p.so_w, phw = ph % p.so_w;
+    const int Hp = p.Hp[phh], Wp = p.Wp[phw];
+    const int Mp = p.N * Hp * Wp;
+    const int tap0 = p.tap_begin[ph];
+    const int ntap = p.tap_begin[ph + 1] - tap0;
+    const int Ka = p.Ka;
+    for (int i = threadIdx.x; i < ntap * CC * Ka; i += 256) {
+        const int t = i / (CC * Ka);
+        const int rem = i - t * CC * Ka;
+        const int c = rem / Ka, k = rem - c * Ka;
+        s_w[i] = p.Wt[(int64_t)p.taps[tap0 + t].widx * p.w_tap_stride + (int64_t)c * p.w_ns + (int64_t)k * p.w_ks];
+    }
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= Mp) return;
+    const int n = m / (Hp * Wp);
+    const int rem = m - n * (Hp * Wp);
+    const int ohp = rem / Wp, owp = rem - ohp * Wp;
+    float acc[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+    for (int t = 0; t < ntap; ++t) {
+        const IgemmTap tap = p.taps[tap0 + t];
+        const int ih = ohp * p.sa_h + tap.dh, iw = owp * p.sa_w + tap.dw;
+        if ((unsigned)ih >= (unsigned)p.Ha || (unsigned)iw >= (unsigned)p.Wa) continue;
+        const float* src = p.A + (int64_t)((n * p.Ha + ih) * p.Wa + iw) * p.a_ld;
+        const float* w = s_w + t * CC * Ka;
+        for (int k = 0; k < Ka; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + k);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + c * Ka + k);
+                acc[c] = fmaf(v.x, wv.x, acc[c]);
+                acc[c] = fmaf(v.y, wv.y, acc[c]);
+                acc[c] = fmaf(v.z, wv.z, acc[c]);
+                acc[c] = fmaf(v.w, wv.w, acc[c]);
+            }
+        }
+    }
+    const int64_t pix = (int64_t)(n * p.Hc + ohp * p.so_h + phh) * p.Wc + owp * p.so_w + phw;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) p.Out[pix * p.c_ld + c] = epilogue_value(p, acc[c], pix, c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// filtgrad: df[tap][c][k] = sum_m img[pix(m,tap)][c] * feat[m][k].  The reduction runs over output
+// pixels, so both MFMA operands are read straight from global memory in operand layout
+// (A[i=c][k=pixel], B[k=pixel][j=k]: 128-byte channel rows, coalesced); L1/L2 absorb the re-reads
+// across the 4 waves of a block, which work on neighbouring taps of the same tile.
+// Split over pixel slabs; partial filters are summed by reduce_slabs_kernel in a fixed order
+// (no float atomics: results are run-to-run reproducible).
+struct FiltgradParams {
+    const float* img; const float* feat;
+    float* out;          // [nslab][ntap][Cf][K]  (the final df when nslab == 1)
+    float* bias_out;     // [nslab][K] or null
+    int N, H, W, C, img_ld;
+    int Ho, Wo, K, feat_ld;
+    int kw, sh, sw, pt, pl;
+    int fold, Cf, ntap;
+    int ctiles, ktiles;
+    int rows_total, rows_per_slab;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int item = blockIdx.x * 4 + wave;                 // over [ctile][ktile][tap], tap fastest
+    if (item >= p.ctiles * p.ktiles * p.ntap) return;
+    const int tap = item % p.ntap;
+    const int kt = (item / p.ntap) % p.ktiles;
+    const int ct = item / (p.ntap * p.ktiles);
+    const int c0 = ct * 32, k0 = kt * 32 * NT;
+    const int slab = blockIdx.y;
+    const int row_begin = slab * p.rows_per_slab;
+    const int row_end = min(row_begin + p.rows_per_slab, p.rows_total);
+    const int tp = p.fold ? tap : tap / p.kw;
+    const int tq = p.fold ? 0 : tap % p.kw;
+    const bool do_bias = p.bias_out != nullptr && tap == 0 && ct == 0;
+
+    const int e = c0 + li;                                  // channel (or folded (q,c)) index of this lane
+    const int eq = p.fold ? e / p.C : 0;
+    const bool e_ok = e < p.Cf;
+
+    f32x16 acc[NT];
+    float sb[NT];
+#pragma unroll
+    for (int y = 0; y < NT; ++y) {
+        sb[y] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+    }
+    bool k_ok[NT];
+#pragma unroll
+    for (int y = 0; y < NT; ++y) k_ok[y] = (k0 + y * 32 + li) < p.K;
+
+    for (int row = row_begin; row < row_end; ++row) {
+        const int n = row / p.Ho, ho = row - n * p.Ho;
+        const int ih = ho * p.sh + tp - p.pt;
+        const bool row_ok = (unsigned)ih < (unsigned)p.H;
+        if (!row_ok && !do_bias) continue;
+        const float* irow = p.img + (int64_t)((n * p.H + (row_ok ? ih : 0)) * p.W) * p.img_ld + e;
+        const float* frow = p.feat + (int64_t)(row * p.Wo) * p.feat_ld + k0 + li;
+#pragma unroll 4
+        for (int wo = 0; wo < p.Wo; wo += 2) {
+            const int wp = wo + lh;
+            const int iw0 = wp * p.sw + tq - p.pl;
+            const bool a_ok = row_ok && e_ok && wp < p.Wo && (unsigned)(iw0 + eq) < (unsigned)p.W;
+            const float a = a_ok ? irow[(int64_t)iw0 * p.img_ld] : 0.f;
+            float b[NT];
+#pragma unroll
+            for (int y = 0; y < NT; ++y) b[y] = (wp < p.Wo && k_ok[y]) ? frow[(int64_t)wp * p.feat_ld + y * 32] : 0.f;
+#pragma unroll
+            for (int y = 0; y < NT; ++y) {
+                acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[y], acc[y], 0, 0, 0);
+                sb[y] += b[y];
+            }
+        }
+    }
+    float* out = p.out + ((int64_t)slab * p.ntap + tap) * p.Cf * p.K;
+#pragma unroll
+    for (int y = 0; y < NT; ++y) {
+        const int k = k0 + y * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (c < p.Cf && k < p.K) out[(int64_t)c * p.K + k] = acc[y][r];
+        }
+        if (do_bias) {
+            const float s = sb[y] + __shfl_xor(sb[y], 32);
+            if (lh == 0 && k < p.K) p.bias_out[(int64_t)slab * p.K + k] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, int nslab, int64_t count,
+                                                          float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += part[(int64_t)k * count + i];
+        out[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int check_geom(const mv3d_conv_geom* g, const char* who) {
+    if (!g) return fail(MV3D_E_INVAL, "%s: null geometry", who);
+    if (g->dtype != MV3D_F32) return fail(MV3D_E_UNSUPPORTED, "%s: dtype %d not supported (fp32 only)", who, g->dtype);
+    if (g->N <= 0 || g->H <= 0 || g->W <= 0 || g->C <= 0 || g->K <= 0) return fail(MV3D_E_INVAL, "%s: non-positive dimension", who);
+    if (g->kh <= 0 || g->kw <= 0 || g->kh * g->kw > 36) return fail(MV3D_E_INVAL, "%s: filter %dx%d unsupported", who, g->kh, g->kw);
+    if (g->sh < 1 || g->sh > 2 || g->sw < 1 || g->sw > 2) return fail(MV3D_E_UNSUPPORTED, "%s: stride %dx%d unsupported (1 or 2)", who, g->sh, g->sw);
+    if (g->Ho != cdiv(g->H, g->sh) || g->Wo != cdiv(g->W, g->sw))
+        return fail(MV3D_E_INVAL, "%s: feature size %dx%d is not ceil(%d/%d) x ceil(%d/%d) (SAME)", who, g->Ho, g->Wo, g->H, g->sh, g->W, g->sw);
+    if (g->img_ld < g->C || g->feat_ld < g->K) return fail(MV3D_E_INVAL, "%s: pixel stride smaller than channel count", who);
+    if ((int64_t)g->N * g->H * g->W >= (1ll << 31) || (int64_t)g->N * g->Ho * g->Wo * 1 >= (1ll << 31))
+        return fail(MV3D_E_UNSUPPORTED, "%s: more than 2^31 pixels", who);
+    return MV3D_OK;
+}
+
+static void fill_epilogue(IgemmParams& p, const mv3d_epilogue* e) {
+    p.bias = nullptr; p.act = MV3D_ACT_NONE; p.leak = 0.2f;
+    p.gact = MV3D_ACT_NONE; p.gleak = 0.2f; p.gref = nullptr; p.g_ld = 0;
+    if (!e) return;
+    p.bias = (const float*)e->bias; p.act = e->act; p.leak = e->leak;
+    p.gact = e->gmask_act; p.gleak = e->gmask_leak; p.gref = (const float*)e->gmask_ref; p.g_ld = e->gmask_ld;
+}
+
+static int check_epilogue(const mv3d_epilogue* e, const char* who) {
+    if (!e) return MV3D_OK;
+    if (e->act < 0 || e->act > MV3D_ACT_TANH || e->gmask_act < 0 || e->gmask_act > MV3D_ACT_TANH)
+        return fail(MV3D_E_INVAL, "%s: bad activation enum", who);
+    if (e->gmask_act != MV3D_ACT_NONE && !e->gmask_ref) return fail(MV3D_E_INVAL, "%s: gmask_act without gmask_ref", who);
+    return MV3D_OK;
+}
+
+template <int WM, int MT, int NT>
+static void launch_igemm_cfg(const IgemmParams& p, bool vec, bool bkmajor, dim3 grid, hipStream_t s) {
+    if (vec) {
+        if (bkmajor) igemm_kernel<WM, MT, NT, true, true><<<grid, 256, 0, s>>>(p);
+        else igemm_kernel<WM, MT, NT, true, false><<<grid, 256, 0, s>>>(p);
+    } else {
+        if (bkmajor) igemm_kernel<WM, MT, NT, false, true><<<grid, 256, 0, s>>>(p);
+        else igemm_kernel<WM, MT, NT, false, false><<<grid, 256, 0, s>>>(p);
+    }
+}
+
+static size_t igemm_plan(IgemmParams& p, int* cfg_out, dim3* grid_out) {
+    // tile selection: wide N tiles when the output has the channels, small M tiles when there are few pixels
+    int maxMp = p.N * p.Hp[0] * p.Wp[0];
+    int nphase = p.so_h * p.so_w;
+    int cfg, BM, BN;
+    if (p.Cc > 32) { cfg = (maxMp >= 128 * 512) ? 1 : 2; }      // 128x64 or 64x64
+    else cfg = 0;                                                 // 128x32
+    if (cfg == 0 && maxMp < 128 * 256) cfg = 3;                   // 64x32 is not instantiated; use 64x64 anyway
+    if (cfg == 3) cfg = 2;
+    if (cfg == 0) { BM = 128; BN = 32; }
+    else if (cfg == 1) { BM = 128; BN = 64; }
+    else { BM = 64; BN = 64; }
+    int gx = cdiv(maxMp, BM), gy = cdiv(p.Cc, BN);
+    int blocks = gx * gy * nphase;
+    int min_iters = 1 << 30;
+    for (int ph = 0; ph < nphase; ++ph) {
+        int it = (p.tap_begin[ph + 1] - p.tap_begin[ph]) * cdiv(p.Ka, 32);
+        if (it < min_iters) min_iters = it;
+    }
+    int ksplit = 1;
+    if (blocks < 384 && min_iters >= 8) {
+        ksplit = cdiv(768, blocks);
+        if (ksplit > min_iters / 4) ksplit = min_iters / 4;
+        if (ksplit > 32) ksplit = 32;
+        if (ksplit < 1) ksplit = 1;
+    }
+    p.ksplit = ksplit;
+    *cfg_out = cfg;
+    *grid_out = dim3(gx, gy, nphase * ksplit);
+    return ksplit > 1 ? (size_t)ksplit * p.N * p.Hc * p.Wc * p.Cc * sizeof(float) : 0;
+}
+
+static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, const char* who) {
+    const bool bkmajor = (p.w_ns == 1);
+    const bool vec = !p.fold && (p.Ca % 4 == 0) && (p.a_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    if (!bkmajor && p.Cc <= 4 && p.so_h * p.so_w <= 4 && (p.Ka % 4 == 0) && (p.a_ld % 4 == 0) &&
+        ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0) && p.Ka <= 512) {
+        // thin image-side output -> VALU kernel
+        int maxMp = p.N * p.Hp[0] * p.Wp[0];
+        int maxtap = 0;
+        for (int ph = 0; ph < p.so_h * p.so_w; ++ph) maxtap = std::max(maxtap, p.tap_begin[ph + 1] - p.tap_begin[ph]);
+        size_t lds = (size_t)maxtap * p.Cc * p.Ka * sizeof(float);
+        if (lds <= 64 * 1024) {
+            dim3 grid(cdiv(maxMp, 256), 1, p.so_h * p.so_w);
+            p.ksplit = 1;
+            return dispatch(stream, [=](hipStream_t s) {
+                switch (p.Cc) {
+                    case 1: thin_feat2img_kernel<1><<<grid, 256, lds, s>>>(p); break;
+                    case 2: thin_feat2img_kernel<2><<<grid, 256, lds, s>>>(p); break;
+                    case 3: thin_feat2img_kernel<3><<<grid, 256, lds, s>>>(p); break;
+                    default: thin_feat2img_kernel<4><<<grid, 256, lds, s>>>(p); break;
+                }
+                return launched("thin_feat2img_kernel");
+            });
+        }
+    }
+    int cfg; dim3 grid;
+    size_t need = igemm_plan(p, &cfg, &grid);
+    if (need > ws_bytes || (need && !ws)) {
+        // not enough scratch for split-K: fall back to a single pass (still correct)
+        p.ksplit = 1;
+        grid.z = p.so_h * p.so_w;
+        need = 0;
+    }
+    p.Part = (float*)ws;
+    return dispatch(stream, [=](hipStream_t s) {
+        if (cfg == 0) launch_igemm_cfg<4, 1, 1>(p, vec, bkmajor, grid, s);
+        else if (cfg == 1) launch_igemm_cfg<4, 1, 2>(p, vec, bkmajor, grid, s);
+        else launch_igemm_cfg<2, 1, 1>(p, vec, bkmajor, grid, s);
+        int rc = launched(who);
+        if (rc != MV3D_OK) return rc;
+        if (p.ksplit > 1) {
+            int64_t total = (int64_t)p.N * p.Hc * p.Wc * p.Cc;
+            int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
+            igemm_splitk_epilogue<<<blocks, 256, 0, s>>>(p);
+            rc = launched("igemm_splitk_epilogue");
+        }
+        return rc;
+    });
+}
+
+// image side -> feature side (conv fwd / deconv dgrad)
+static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, void* feat, const mv3d_epilogue* epi,
+                    void* ws, size_t ws_bytes, void* stream, const char* who) {
+    int rc = check_geom(g, who);
+    if (rc == MV3D_OK) rc = check_epilogue(epi, who);
+    if (rc != MV3D_OK) return rc;
+    if (!img || !w || !feat) return fail(MV3D_E_INVAL, "%s: null tensor pointer", who);
+    IgemmParams p = {};
+    int ho, wo, pt, pl;
+    same_pad(g->H, g->kh, g->sh, &ho, &pt);
+    same_pad(g->W, g->kw, g->sw, &wo, &pl);
+    p.A = (const float*)img; p.Wt = (const float*)w; p.Out = (float*)feat;
+    p.N = g->N; p.Ha = g->H; p.Wa = g->W; p.Ca = g->C; p.a_ld = g->img_ld;
+    p.Hc = g->Ho; p.Wc = g->Wo; p.Cc = g->K; p.c_ld = g->feat_ld;
+    p.sa_h = g->sh; p.sa_w = g->sw; p.so_h = 1; p.so_w = 1;
+    p.Hp[0] = g->Ho; p.Wp[0] = g->Wo; p.Hp[1] = 0; p.Wp[1] = 0;
+    p.fold = (g->C < 16 && g->img_ld == g->C && g->kw > 1) ? 1 : 0;
+    int nt = 0;
+    if (p.fold) {
+        for (int pp = 0; pp < g->kh; ++pp) { p.taps[nt].dh = (int8_t)(pp - pt); p.taps[nt].dw = (int8_t)(-pl); p.taps[nt].widx = (int16_t)(pp * g->kw); ++nt; }
+        p.Ka = g->kw * g->C;
+    } else {
+        for (int pp = 0; pp < g->kh; ++pp)
+            for (int q = 0; q < g->kw; ++q) { p.taps[nt].dh = (int8_t)(pp - pt); p.taps[nt].dw = (int8_t)(q - pl); p.taps[nt].widx = (int16_t)(pp * g->kw + q); ++nt; }
+        p.Ka = g->C;
+    }
+    p.tap_begin[0] = 0; p.tap_begin[1] = nt;
+    p.w_tap_stride = g->C * g->K; p.w_ks = g->K; p.w_ns = 1;
+    fill_epilogue(p, epi);
+    return run_igemm(p, ws, ws_bytes, stream, who);
+}
+
+// feature side -> image side (conv dgrad / deconv fwd), one dense sub-convolution per stride phase
+static int feat2img(const mv3d_conv_geom* g, const void* feat, const void* w, void* img, const mv3d_epilogue* epi,
+                    void* ws, size_t ws_bytes, void* stream, const char* who) {
+    int rc = check_geom(g, who);
+    if (rc == MV3D_OK) rc = check_epilogue(epi, who);
+    if (rc != MV3D_OK) return rc;
+    if (!img || !w || !feat) return fail(MV3D_E_INVAL, "%s: null tensor pointer", who);
+    IgemmParams p = {};
+    int ho, wo, pt, pl;
+    same_pad(g->H, g->kh, g->sh, &ho, &pt);
+    same_pad(g->W, g->kw, g->sw, &wo, &pl);
+    p.A = (const float*)feat; p.Wt = (const float*)w; p.Out = (float*)img;
+    p.N = g->N; p.Ha = g->Ho; p.Wa = g->Wo; p.Ca = g->K; p.a_ld = g->feat_ld;
+    p.Hc = g->H; p.Wc = g->W; p.Cc = g->C; p.c_ld = g->img_ld;
+    p.sa_h = 1; p.sa_w = 1; p.so_h = g->sh; p.so_w = g->sw;
+    for (int a = 0; a < 2; ++a) {
+        p.Hp[a] = a < g->sh ? (g->H - a + g->sh - 1) / g->sh : 0;
+        p.Wp[a] = a < g->sw ? (g->W - a + g->sw - 1) / g->sw : 0;
+    }
+    int nt = 0;
+    for (int phh = 0; phh < g->sh; ++phh)
+        for (int phw = 0; phw < g->sw; ++phw) {
+            p.tap_begin[phh * g->sw + phw] = nt;
+            const int p0 = (phh + pt) % g->sh, q0 = (phw + pl) % g->sw;
+            for (int pp = p0; pp < g->kh; pp += g->sh)
+                for (int q = q0; q < g->kw; q += g->sw) {
+                    // u = s*u' + ph, tap p: i = (u + pt - p)/s = u' + (ph + pt - p)/s  (exact division)
+                    p.taps[nt].dh = (int8_t)((phh + pt - pp) / g->sh);
+                    p.taps[nt].dw = (int8_t)((phw + pl - q) / g->sw);
+                    p.taps[nt].widx = (int16_t)(pp * g->kw + q);
+                    ++nt;
+                }
+        }
+    p.tap_begin[g->sh * g->sw] = nt;
+    p.fold = 0; p.Ka = g->K;
+    p.w_tap_stride = g->C * g->K; p.w_ks = 1; p.w_ns = g->K;
+    fill_epilogue(p, epi);
+    return run_igemm(p, ws, ws_bytes, stream, who);
+}
+
+static void filtgrad_plan(const mv3d_conv_geom* g, FiltgradParams& p, int* nt_out, int* nslab_out) {
+    int ho, wo;
+    same_pad(g->H, g->kh, g->sh, &ho, &p.pt);
+    same_pad(g->W, g->kw, g->sw, &wo, &p.pl);
+    p.N = g->N; p.H = g->H; p.W = g->W; p.C = g->C; p.img_ld = g->img_ld;
+    p.Ho = g->Ho; p.Wo = g->Wo; p.K = g->K; p.feat_ld = g->feat_ld;
+    p.kw = g->kw; p.sh = g->sh; p.sw = g->sw;
+    p.fold = (g->C < 16 && g->img_ld == g->C && g->kw > 1) ? 1 : 0;
+    p.Cf = p.fold ? g->kw * g->C : g->C;
+    p.ntap = p.fold ? g->kh : g->kh * g->kw;
+    const int NT = (g->K > 32) ? 2 : 1;
+    p.ctiles = cdiv(p.Cf, 32);
+    p.ktiles = cdiv(g->K, 32 * NT);
+    p.rows_total = g->N * g->Ho;
+    const int items = p.ctiles * p.ktiles * p.ntap;
+    const int blocks_x = cdiv(items, 4);
+    int nslab = cdiv(2048, blocks_x);
+    if (nslab > p.rows_total) nslab = p.rows_total;
+    // do not split below ~64 pixel pairs of work per slab
+    int min_rows = cdiv(128, g->Wo);
+    if (nslab > cdiv(p.rows_total, min_rows)) nslab = cdiv(p.rows_total, min_rows);
+    if (nslab < 1) nslab = 1;
+    p.rows_per_slab = cdiv(p.rows_total, nslab);
+    nslab = cdiv(p.rows_total, p.rows_per_slab);
+    *nt_out = NT;
+    *nslab_out = nslab;
+}
+
+static size_t filtgrad_ws_bytes(const mv3d_conv_geom* g) {
+    FiltgradParams p = {};
+    int NT, nslab;
+    filtgrad_plan(g, p, &NT, &nslab);
+    if (nslab == 1) return 0;
+    return (size_t)nslab * ((size_t)g->kh * g->kw * g->C * g->K + g->K) * sizeof(float);
+}
+
+static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, void* df, void* db,
+                    void* ws, size_t ws_bytes, void* stream, const char* who) {
+    int rc = check_geom(g, who);
+    if (rc != MV3D_OK) return rc;
+    if (!img || !feat || !df) return fail(MV3D_E_INVAL, "%s: null tensor pointer", who);
+    FiltgradParams p = {};
+    int NT, nslab;
+    filtgrad_plan(g, p, &NT, &nslab);
+    const int64_t fcount = (int64_t)g->kh * g->kw * g->C * g->K;
+    p.img = (const float*)img; p.feat = (const float*)feat;
+    if (nslab > 1) {
+        size_t need = (size_t)nslab * (fcount + g->K) * sizeof(float);
+        if (!ws || ws_bytes < need) return fail(MV3D_E_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
+        p.out = (float*)ws;
+        p.bias_out = db ? (float*)ws + (int64_t)nslab * fcount : nullptr;
+    } else {
+        p.out = (float*)df;
+        p.bias_out = (float*)db;
+    }
+    dim3 grid(cdiv(p.ctiles * p.ktiles * p.ntap, 4), nslab);
+    float* dfp = (float*)df; float* dbp = (float*)db;
+    const int K = g->K;
+    return dispatch(stream, [=](hipStream_t s) {
+        if (NT == 2) filtgrad_kernel<2><<<grid, 256, 0, s>>>(p);
+        else filtgrad_kernel<1><<<grid, 256, 0, s>>>(p);
+        int r = launched(who);
+        if (r != MV3D_OK || nslab == 1) return r;
+        reduce_slabs_kernel<<<(int)std::min<int64_t>(cdiv64(fcount, 256), 2048), 256, 0, s>>>(p.out, nslab, fcount, dfp);
+        if (dbp) reduce_slabs_kernel<<<cdiv(K, 256), 256, 0, s>>>(p.bias_out, nslab, K, dbp);
+        return launched("reduce_slabs_kernel");
+    });
+}
+
+}  // namespace mv3d
+
+using namespace mv3d;
+
+extern "C" {
+
+int mv3d_conv2d_fwd(const mv3d_conv_geom* g, const void* x, const void* w, void* y, const mv3d_epilogue* epi,
+                    void* ws, size_t wsb, void* stream) {
+    return img2feat(g, x, w, y, epi, ws, wsb, stream, "mv3d_conv2d_fwd");
+}
+int mv3d_conv2d_dgrad(const mv3d_conv_geom* g, const void* dy, const void* w, void* dx, const mv3d_epilogue* epi,
+                      void* ws, size_t wsb, void* stream) {
+    return feat2img(g, dy, w, dx, epi, ws, wsb, stream, "mv3d_conv2d_dgrad");
+}
+int mv3d_conv2d_wgrad(const mv3d_conv_geom* g, const void* x, const void* dy, void* dw, void* db,
+                      void* ws, size_t wsb, void* stream) {
+    return filtgrad(g, x, dy, dw, db, ws, wsb, stream, "mv3d_conv2d_wgrad");
+}
+int mv3d_deconv2d_fwd(const mv3d_conv_geom* g, const void* x, const void* w, void* y, const mv3d_epilogue* epi,
+                      void* ws, size_t wsb, void* stream) {
+    return feat2img(g, x, w, y, epi, ws, wsb, stream, "mv3d_deconv2d_fwd");
+}
+int mv3d_deconv2d_dgrad(const mv3d_conv_geom* g, const void* dy, const void* w, void* dx, const mv3d_epilogue* epi,
+                        void* ws, size_t wsb, void* stream) {
+    return img2feat(g, dy, w, dx, epi, ws, wsb, stream, "mv3d_deconv2d_dgrad");
+}
+int mv3d_deconv2d_wgrad(const mv3d_conv_geom* g, const void* x, const void* dy, void* dw, void* ws, size_t wsb, void* stream) {
+    return filtgrad(g, dy, x, dw, nullptr, ws, wsb, stream, "mv3d_deconv2d_wgrad");
+}
+
+size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g) {
+    if (!g || check_geom(g, "mv3d_conv_workspace_bytes") != MV3D_OK) return 0;
+    // split-K partials of either direction: at most 32 slabs of the larger output
+    size_t out_img = (size_t)g->N * g->H * g->W * g->C, out_feat = (size_t)g->N * g->Ho * g->Wo * g->K;
+    size_t big = out_img > out_feat ? out_img : out_feat;
+    size_t igemm = 0;
+    {   // replay the planner for both directions to get the exact split
+        IgemmParams p = {};
+        int cfg; dim3 grid;
+        p.N = g->N; p.Hc = g->Ho; p.Wc = g->Wo; p.Cc = g->K; p.so_h = p.so_w = 1; p.Hp[0] = g->Ho; p.Wp[0] = g->Wo;
+        const bool fold = (g->C < 16 && g->img_ld == g->C && g->kw > 1);
+        p.Ka = fold ? g->kw * g->C : g->C; p.tap_begin[0] = 0; p.tap_begin[1] = fold ? g->kh : g->kh * g->kw;
+        size_t a = igemm_plan(p, &cfg, &grid);
+        igemm = a;
+        (void)big;
+        IgemmParams q = {};
+        q.N = g->N; q.Hc = g->H; q.Wc = g->W; q.Cc = g->C; q.so_h = g->sh; q.so_w = g->sw;
+        for (int i = 0; i < 2; ++i) { q.Hp[i] = i < g->sh ? (g->H - i + g->sh - 1) / g->sh : 0; q.Wp[i] = i < g->sw ? (g->W - i + g->sw - 1) / g->sw : 0; }
+        q.Ka = g->K;
+        int ho, wo, pt, pl;
+        same_pad(g->H, g->kh, g->sh, &ho, &pt);
+        same_pad(g->W, g->kw, g->sw, &wo, &pl);
+        int nt = 0;
+        for (int phh = 0; phh < g->sh; ++phh)
+            for (int phw = 0; phw < g->sw; ++phw) {
+                q.tap_begin[phh * g->sw + phw] = nt;
+                for (int pp = (phh + pt) % g->sh; pp < g->kh; pp += g->sh)
+                    for (int qq = (phw + pl) % g->sw; qq < g->kw; qq += g->sw) ++nt;
+            }
+        q.tap_begin[g->sh * g->sw] = nt;
+        size_t b = igemm_plan(q, &cfg, &grid);
+        if (b > igemm) igemm = b;
+    }
+    size_t fg = filtgrad_ws_bytes(g);
+    return igemm > fg ? igemm : fg;
+}
+
+// ---- linear layers as 1x1 "convolutions" over a 1 x B image (tf_utils.py:67) -------------------
+static void fc_geom(mv3d_conv_geom& g, int B, int in, int out, int x_ld, int y_ld) {
+    g.N = 1; g.H = 1; g.W = B; g.C = in; g.Ho = 1; g.Wo = B; g.K = out;
+    g.kh = g.kw = g.sh = g.sw = 1; g.img_ld = x_ld; g.feat_ld = y_ld; g.dtype = MV3D_F32;
+}
+int mv3d_fc_fwd(int B, int in, int out, const void* x, int x_ld, const void* M, void* y, int y_ld,
+                const mv3d_epilogue* epi, void* ws, size_t wsb, void* stream) {
+    mv3d_conv_geom g; fc_geom(g, B, in, out, x_ld, y_ld);
+    return img2feat(&g, x, M, y, epi, ws, wsb, stream, "mv3d_fc_fwd");
+}
+int mv3d_fc_dgrad(int B, int in, int out, const void* dy, int dy_ld, const void* M, void* dx, int dx_ld,
+                  const mv3d_epilogue* epi, void* ws, size_t wsb, void* stream) {
+    mv3d_conv_geom g; fc_geom(g, B, in, out, dx_ld, dy_ld);
+    return feat2img(&g, dy, M, dx, epi, ws, wsb, stream, "mv3d_fc_dgrad");
+}
+int mv3d_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* dM, void* db,
+                  void* ws, size_t wsb, void* stream) {
+    mv3d_conv_geom g; fc_geom(g, B, in, out, x_ld, dy_ld);
+    return filtgrad(&g, x, dy, dM, db, ws, wsb, stream, "mv3d_fc_wgrad");
+}
+size_t mv3d_fc_workspace_bytes(int B, int in, int out) {
+    mv3d_conv_geom g; fc_geom(g, B, in, out, in, out);
+    return mv3d_conv_workspace_bytes(&g);
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+// HBM-bound pieces of the train step: warp + bilinear resampler (fwd / grad wrt flow), pixel
+// losses, fused TF-Adam, activation fwd/bwd, strided copies.  Built with -ffp-contract=off so the
+// fp32 expressions round exactly like the reference's unfused TF kernels (and the numpy oracle).
+#include "common.h"
+#include <algorithm>
+
+namespace mv3d {
+
+// ---------------------------------------------------------------- warp_pts_layer + resample_layer
+// tf_utils.py:35-52 + tf.contrib.resampler.  Output pixel (i,j):
+//   x = flow[...,0] + i   (ROW index added to the channel the resampler reads as x / column)
+//   y = flow[...,1] + j
+// Block = 8 x 32 output pixels; one wave covers 2 x 32 pixels, so its source footprint is the
+// transposed 32 x 2 (+flow) patch and stays in L1/L2.
+struct ResampleParams {
+    const float* src; const float* flow; const float* dgen;
+    float* warp; float* gen; float* dflow;
+    int N, H, W, Hs, Ws, C, flow_ld, dflow_ld;
+};
+
+__device__ __forceinline__ float tap(const float* img, int Ws, int Hs, int C, int y, int x, int c) {
+    return ((unsigned)x < (unsigned)Ws && (unsigned)y < (unsigned)Hs) ? img[((int64_t)y * Ws + x) * C + c] : 0.f;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void resample_kernel(const ResampleParams p) {
+    const int tj = threadIdx.x & 31, ti = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + tj, i = blockIdx.y * 8 + ti, n = blockIdx.z;
+    if (i >= p.H || j >= p.W) return;
+    const int64_t pix = ((int64_t)n * p.H + i) * p.W + j;
+    const float* fl = p.flow + pix * p.flow_ld;
+    const float x = fl[0] + (float)i;
+    const float y = fl[1] + (float)j;
+    if (!BWD && p.warp) { p.warp[pix * 2] = x; p.warp[pix * 2 + 1] = y; }
+    const bool valid = x > -1.0f && y > -1.0f && x < (float)p.Ws && y < (float)p.Hs;
+    const float fxf = floorf(x), fyf = floorf(y);
+    const int fx = (int)fxf, fy = (int)fyf, cx = fx + 1, cy = fy + 1;
+    const float dx = (fxf + 1.0f) - x, dy = (fyf + 1.0f) - y;
+    const float* img = p.src + (int64_t)n * p.Hs * p.Ws * p.C;
+    if (!BWD) {
+        float* out = p.gen + pix * p.C;
+        for (int c = 0; c < p.C; ++c) {
+            float v = 0.f;
+            if (valid) {
+                const float iff = tap(img, p.Ws, p.Hs, p.C, fy, fx, c), icc = tap(img, p.Ws, p.Hs, p.C, cy, cx, c);
+                const float ifc = tap(img, p.Ws, p.Hs, p.C, cy, fx, c), icf = tap(img, p.Ws, p.Hs, p.C, fy, cx, c);
+                v = ((dx * dy * iff + (1.0f - dx) * (1.0f - dy) * icc) + dx * (1.0f - dy) * ifc) + (1.0f - dx) * dy * icf;
+            }
+            out[c] = v;
+        }
+    } else {
+        float gx = 0.f, gy = 0.f;
+        if (valid) {
+            const float* g = p.dgen + pix * p.C;
+            for (int c = 0; c < p.C; ++c) {
+                const float iff = tap(img, p.Ws, p.Hs, p.C, fy, fx, c), icc = tap(img, p.Ws, p.Hs, p.C, cy, cx, c);
+                const float ifc = tap(img, p.Ws, p.Hs, p.C, cy, fx, c), icf = tap(img, p.Ws, p.Hs, p.C, fy, cx, c);
+                gx += g[c] * (dy * (icf - iff) + (1.0f - dy) * (icc - ifc));
+                gy += g[c] * (dx * (ifc - iff) + (1.0f - dx) * (icc - icf));
+            }
+        }
+        float* d = p.dflow + pix * p.dflow_ld;
+        d[0] = gx; d[1] = gy;
+    }
+}
+
+// ---------------------------------------------------------------- pixel losses (tf_utils.py:18-23)
+__global__ __launch_bounds__(256) void pixel_loss_kernel(int64_t pixels, int ch, const float* __restrict__ a,
+                                                        const float* __restrict__ b, const float* __restrict__ mask,
+                                                        int kind, float weight, float* loss, float* __restrict__ grad) {
+    const int64_t total = pixels * ch;
+    const float gscale = (kind == 2 ? 2.0f : 1.0f) * weight / (float)pixels;
+    float sum = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float m = mask ? mask[i / ch] : 1.0f;
+        const float d = (a[i] - b[i]) * m;
+        float g;
+        if (kind == 2) { sum += d * d; g = d * m * gscale; }
+        else { sum += fabsf(d); g = ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) * m * gscale; }
+        if (grad) grad[i] = g;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    __shared__ float s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (weight / (float)pixels));
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t count, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) dst[i] = v;
+}
+
+// ---------------------------------------------------------------- Adam (TF ApplyAdam)
+// One pass: 16 B per lane loads of p, g, m, v and stores of p, m, v = 28 B/param of HBM traffic.
+__global__ __launch_bounds__(256) void adam_kernel(int64_t count, float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ m, float* __restrict__ v, float alpha,
+                                                  float omb1, float omb2, float eps, float gscale) {
+    const int64_t nvec = count >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ge[k] * gscale;
+            me[k] += (gk - me[k]) * omb1;
+            ve[k] += (gk * gk - ve[k]) * omb2;
+            pe[k] -= (me[k] * alpha) / (sqrtf(ve[k]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const int64_t i = (nvec << 2) + threadIdx.x;
+        const float gk = g[i] * gscale;
+        m[i] += (gk - m[i]) * omb1;
+        v[i] += (gk * gk - v[i]) * omb2;
+        p[i] -= (m[i] * alpha) / (sqrtf(v[i]) + eps);
+    }
+}
+
+// ---------------------------------------------------------------- activations / copies
+__global__ __launch_bounds__(256) void act_fwd_kernel(int64_t rows, int ch, const float* x, int x_ld, float* y, int y_ld,
+                                                     int act, float leak) {
+    const int64_t total = rows * ch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ch; const int c = (int)(i - r * ch);
+        y[r * y_ld + c] = act_apply(x[r * x_ld + c], act, leak);
+    }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(int64_t rows, int ch, const float* dy, int dy_ld, const float* ref,
+                                                     int ref_ld, float* dx, int dx_ld, int act, float leak) {
+    const int64_t total = rows * ch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ch; const int c = (int)(i - r * ch);
+        dx[r * dx_ld + c] = dy[r * dy_ld + c] * act_grad_from_out(ref[r * ref_ld + c], act, leak);
+    }
+}
+__global__ __launch_bounds__(256) void copy2d_kernel(int64_t rows, int ch, const float* src, int64_t src_ld, int64_t src_row_div,
+                                                    float* dst, int64_t dst_ld, int accumulate) {
+    const int64_t total = rows * ch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ch; const int c = (int)(i - r * ch);
+        const float v = src[(r / src_row_div) * src_ld + c];
+        float* d = dst + r * dst_ld + c;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+__global__ __launch_bounds__(256) void group_sum_kernel(int64_t groups, int group, int ch, const float* src, int64_t src_ld,
+                                                       float* dst, int64_t dst_ld) {
+    const int64_t total = groups * ch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t gidx = i / ch; const int c = (int)(i - gidx * ch);
+        float s = 0.f;
+        for (int r = 0; r < group; ++r) s += src[(gidx * group + r) * src_ld + c];
+        dst[gidx * dst_ld + c] = s;
+    }
+}
+
+static inline int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv64(total, 256), 8192); }
+
+}  // namespace mv3d
+
+using namespace mv3d;
+
+extern "C" {
+
+int mv3d_warp_resample_fwd(int N, int H, int W, int Hs, int Ws, int C, const void* src, const void* flow, int flow_ld,
+                           void* warp_out, void* gen, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || flow_ld < 2) return fail(MV3D_E_INVAL, "mv3d_warp_resample_fwd: bad shape");
+    if (!src || !flow || !gen) return fail(MV3D_E_INVAL, "mv3d_warp_resample_fwd: null pointer");
+    if (N > 65535) return fail(MV3D_E_UNSUPPORTED, "mv3d_warp_resample_fwd: batch > 65535");
+    ResampleParams p = {(const float*)src, (const float*)flow, nullptr, (float*)warp_out, (float*)gen, nullptr, N, H, W, Hs, Ws, C, flow_ld, 0};
+    dim3 grid(cdiv(W, 32), cdiv(H, 8), N);
+    return dispatch(stream, [=](hipStream_t s) {
+        resample_kernel<false><<<grid, 256, 0, s>>>(p);
+        return launched("resample_kernel<fwd>");
+    });
+}
+
+int mv3d_warp_resample_bwd(int N, int H, int W, int Hs, int Ws, int C, const void* src, const void* flow, int flow_ld,
+                           const void* dgen, void* dflow, int dflow_ld, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || flow_ld < 2 || dflow_ld < 2) return fail(MV3D_E_INVAL, "mv3d_warp_resample_bwd: bad shape");
+    if (!src || !flow || !dgen || !dflow) return fail(MV3D_E_INVAL, "mv3d_warp_resample_bwd: null pointer");
+    if (N > 65535) return fail(MV3D_E_UNSUPPORTED, "mv3d_warp_resample_bwd: batch > 65535");
+    ResampleParams p = {(const float*)src, (const float*)flow, (const float*)dgen, nullptr, nullptr, (float*)dflow, N, H, W, Hs, Ws, C, flow_ld, dflow_ld};
+    dim3 grid(cdiv(W, 32), cdiv(H, 8), N);
+    return dispatch(stream, [=](hipStream_t s) {
+        resample_kernel<true><<<grid, 256, 0, s>>>(p);
+        return launched("resample_kernel<bwd>");
+    });
+}
+
+int mv3d_pixel_loss(int64_t pixels, int ch, const void* a, const void* b, const void* mask, int kind, float weight,
+                    void* loss_accum, void* grad, void* stream) {
+    if (pixels <= 0 || ch <= 0 || (kind != 1 && kind != 2)) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: bad arguments");
+    if (!a || !b || !loss_accum) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: null pointer");
+    const int blocks = (int)std::min<int64_t>(cdiv64(pixels * ch, 256 * 8), 1024);
+    return dispatch(stream, [=](hipStream_t s) {
+        pixel_loss_kernel<<<blocks, 256, 0, s>>>(pixels, ch, (const float*)a, (const float*)b, (const float*)mask, kind, weight,
+                                                (float*)loss_accum, (float*)grad);
+        return launched("pixel_loss_kernel");
+    });
+}
+
+int mv3d_fill(void* dst, int64_t count, float value, void* stream) {
+    if (!dst || count < 0) return fail(MV3D_E_INVAL, "mv3d_fill: bad arguments");
+    if (count == 0) return MV3D_OK;
+    return dispatch(stream, [=](hipStream_t s) {
+        fill_kernel<<<grid_for(count), 256, 0, s>>>((float*)dst, count, value);
+        return launched("fill_kernel");
+    });
+}
+
+int mv3d_adam_step(int64_t count, void* p, const void* g, void* m, void* v, float lr, float beta1, float beta2,
+                   float eps, float beta1_power, float beta2_power, float grad_scale, void* stream) {
+    if (count <= 0 || !p || !g || !m || !v) return fail(MV3D_E_INVAL, "mv3d_adam_step: bad arguments");
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(MV3D_E_INVAL, "mv3d_adam_step: buffers must be 16-byte aligned");
+    // alpha in fp32 exactly as TF's functor evaluates it
+    const float alpha = lr * sqrtf(1.0f - beta2_power) / (1.0f - beta1_power);
+    const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+    const int blocks = (int)std::min<int64_t>(cdiv64(count / 4 + 1, 256), 4096);
+    return dispatch(stream, [=](hipStream_t s) {
+        adam_kernel<<<blocks, 256, 0, s>>>(count, (float*)p, (const float*)g, (float*)m, (float*)v, alpha, omb1, omb2, eps, grad_scale);
+        return launched("adam_kernel");
+    });
+}
+
+int mv3d_act_fwd(int64_t rows, int ch, const void* x, int x_ld, void* y, int y_ld, int act, float leak, void* stream) {
+    if (rows <= 0 || ch <= 0 || !x || !y || x_ld < ch || y_ld < ch) return fail(MV3D_E_INVAL, "mv3d_act_fwd: bad arguments");
+    return dispatch(stream, [=](hipStream_t s) {
+        act_fwd_kernel<<<grid_for(rows * ch), 256, 0, s>>>(rows, ch, (const float*)x, x_ld, (float*)y, y_ld, act, leak);
+        return launched("act_fwd_kernel");
+    });
+}
+
+int mv3d_act_bwd(int64_t rows, int ch, const void* dy, int dy_ld, const void* ref, int ref_ld, void* dx, int dx_ld,
+                 int act, float leak, void* stream) {
+    if (rows <= 0 || ch <= 0 || !dy || !ref || !dx || dy_ld < ch || ref_ld < ch || dx_ld < ch) return fail(MV3D_E_INVAL, "mv3d_act_bwd: bad arguments");
+    return dispatch(stream, [=](hipStream_t s) {
+        act_bwd_kernel<<<grid_for(rows * ch), 256, 0, s>>>(rows, ch, (const float*)dy, dy_ld, (const float*)ref, ref_ld, (float*)dx, dx_ld, act, leak);
+        return launched("act_bwd_kernel");
+    });
+}
+
+int mv3d_copy2d(int64_t rows, int ch, const void* src, int64_t src_ld, int64_t src_row_div, void* dst, int64_t dst_ld,
+                int accumulate, void* stream) {
+    if (rows <= 0 || ch <= 0 || !src || !dst || src_row_div < 1) return fail(MV3D_E_INVAL, "mv3d_copy2d: bad arguments");
+    return dispatch(stream, [=](hipStream_t s) {
+        copy2d_kernel<<<grid_for(rows * ch), 256, 0, s>>>(rows, ch, (const float*)src, src_ld, src_row_div, (float*)dst, dst_ld, accumulate);
+        return launched("copy2d_kernel");
+    });
+}
+
+int mv3d_group_sum(int64_t groups, int group, int ch, const void* src, int64_t src_ld, void* dst, int64_t dst_ld, void* stream) {
+    if (groups <= 0 || group <= 0 || ch <= 0 || !src || !dst) return fail(MV3D_E_INVAL, "mv3d_group_sum: bad arguments");
+    return dispatch(stream, [=](hipStream_t s) {
+        group_sum_kernel<<<grid_for(groups * ch), 256, 0, s>>>(groups, group, ch, (const float*)src, src_ld, (float*)dst, dst_ld);
+        return launched("group_sum_kernel");
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,647 @@
+"""Static graph of the appearance-flow train step, executed by libmv3d_hip.so.
+
+The reference builds a TensorFlow-1.3 graph once (buildModel/build_loss) and then calls
+sess.run([loss, train_op]) per iteration (multi_view_model/train.py:122).  This module is the
+MI355X-side counterpart: the tf_utils-named functions (tf_utils.py of this package) append nodes
+to the current Graph; `finalize()` lays every activation, gradient and variable out in HBM once;
+`compile()` records the forward and the hand-scheduled reverse launch sequences into native plans
+(mv3d_plan_*), so a step is two native calls plus one fused Adam kernel -- no autograd, no
+per-op Python in the steady state.
+
+Data layout in HBM
+  * activations: NHWC fp32, one allocation per root Storage [rows, channels]; tf.concat /
+    tf.split on the channel axis and tf.reshape are views (channel offset + pixel stride `ld`).
+  * gradients: one buffer per root Storage with identical layout.  The gradient buffer of a
+    tensor that is an activation output holds dL/d(pre-activation): the consumer's dgrad kernel
+    multiplies by act'(output) in its epilogue (slope at 0 is f1).
+  * variables: ONE flat fp32 buffer (TF variable order), plus flat grad / Adam m / Adam v buffers
+    of the same layout -> Adam is one kernel launch and the data-parallel all-reduce runs on
+    contiguous bucket views.
+PyTorch is used for device memory (torch.empty), streams and torch.distributed only.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH
+
+_current = []
+
+
+def current_graph():
+    if not _current:
+        raise RuntimeError("no Graph is active: build models inside `with Graph(...) as g:`")
+    return _current[-1]
+
+
+# =============================================================================================== storage / tensors
+class Storage:
+    """[rows, ch] fp32 region.  Either a root allocation, a channel slice of `parent`
+    (set when tf.concat adopts it), or a reshaped alias of a dense root (`alias_of`)."""
+
+    def __init__(self, rows, ch, alias_of=None):
+        self.rows, self.ch = rows, ch
+        self.parent, self.ch_off = None, 0
+        self.alias_of = alias_of
+        self.has_alias = False
+        self.data = None
+        self.grad = None
+        self.needs_grad = False
+        self.external = False
+        if alias_of is not None:
+            alias_of.has_alias = True
+
+    def resolve(self):
+        s, off = self, 0
+        while s.parent is not None:
+            off += s.ch_off
+            s = s.parent
+        return s, off
+
+    def can_be_adopted(self):
+        return self.parent is None and self.alias_of is None and not self.has_alias and not self.external
+
+
+class Tensor:
+    def __init__(self, graph, shape, storage=None, ch_off=0, producer=None, act=ACT_NONE, leak=0.2,
+                 requires_grad=False, name=None):
+        self.graph = graph
+        self.shape = tuple(int(s) for s in shape)
+        self.C = self.shape[-1]
+        self.rows = int(np.prod(self.shape[:-1])) if len(self.shape) > 1 else 1
+        self.storage = storage if storage is not None else Storage(self.rows, self.C)
+        self.ch_off = ch_off
+        self.producer = producer
+        self.act, self.leak = act, leak          # activation these VALUES are the output of
+        self.requires_grad = requires_grad
+        self.name = name
+        self.fused_into = None                   # set on a pre-activation tensor once lrelu()/tanh() fused it
+        self.grad_consumers = 0
+        # backward-emission state
+        self.grad_written = False
+        self.grad_masked = False
+        if requires_grad:
+            self.storage.needs_grad = True
+
+    # ---- TF-like surface
+    def get_shape(self):
+        return list(self.shape)
+
+    # ---- resolved addressing (valid after Graph.finalize())
+    def _root(self):
+        s = self.storage
+        if s.alias_of is not None:
+            root, off = s.alias_of.resolve()
+            assert off == 0 and root.ch == s.alias_of.ch
+            return root, 0, s.ch
+        root, off = s.resolve()
+        return root, off, root.ch
+
+    @property
+    def ld(self):
+        return self._root()[2]
+
+    @property
+    def ptr(self):
+        root, off, _ = self._root()
+        return root.data.data_ptr() + 4 * (off + self.ch_off)
+
+    @property
+    def grad_ptr(self):
+        root, off, _ = self._root()
+        return root.grad.data_ptr() + 4 * (off + self.ch_off)
+
+    def _view(self, buf):
+        root, off, ld = self._root()
+        v = buf.view(-1, ld)[:, off + self.ch_off: off + self.ch_off + self.C]
+        return v.reshape(self.shape) if v.is_contiguous() else v.unflatten(0, self.shape[:-1])
+
+    def value(self):
+        """torch view of the activation (device)."""
+        return self._view(self._root()[0].data)
+
+    def grad_value(self):
+        return self._view(self._root()[0].grad)
+
+    def numpy(self):
+        return self.value().detach().cpu().numpy().copy()
+
+    def set(self, array):
+        t = torch.as_tensor(np.ascontiguousarray(array, dtype=np.float32)) if not torch.is_tensor(array) else array
+        self.value().copy_(t.reshape(self.shape), non_blocking=True)
+
+
+class Variable:
+    def __init__(self, name, shape, init):
+        self.name, self.shape, self.init = name, tuple(shape), init
+        self.size = int(np.prod(shape))
+        self.offset = None
+        self.graph = None
+        self.has_grad = False
+
+    @property
+    def ptr(self):
+        return self.graph.params.data_ptr() + 4 * self.offset
+
+    @property
+    def grad_ptr(self):
+        return self.graph.grads.data_ptr() + 4 * self.offset
+
+    def value(self):
+        return self.graph.params[self.offset:self.offset + self.size].view(self.shape)
+
+    def grad_value(self):
+        return self.graph.grads[self.offset:self.offset + self.size].view(self.shape)
+
+
+class ScalarExpr:
+    """Weighted sum of loss terms; supports the arithmetic the reference applies to losses
+    (main_model.py:144-152: `self.loss = 0.; self.loss += euclidean_loss(...) * factor`)."""
+
+    def __init__(self, terms=()):
+        self.terms = list(terms)          # [(weight, LossTerm)]
+
+    def __add__(self, o):
+        if isinstance(o, (int, float)):
+            if o != 0:
+                raise NotImplementedError("adding a non-zero constant to a loss")
+            return ScalarExpr(self.terms)
+        return ScalarExpr(self.terms + o.terms)
+
+    __radd__ = __add__
+
+    def __mul__(self, c):
+        return ScalarExpr([(w * float(c), t) for w, t in self.terms])
+
+    __rmul__ = __mul__
+
+
+class LossTerm:
+    def __init__(self, a, b, kind, mask=None):
+        self.a, self.b, self.kind, self.mask = a, b, kind, mask
+
+
+# =============================================================================================== nodes
+class Node:
+    def forward(self, g):
+        raise NotImplementedError
+
+    def backward(self, g):
+        pass
+
+
+def _epi(bias=None, act=ACT_NONE, leak=0.2, mask_of=None):
+    """Epilogue for a kernel; mask_of = tensor whose activation derivative multiplies the result."""
+    if mask_of is not None and mask_of.act != ACT_NONE:
+        return _lib.epilogue(bias, act, leak, mask_of.act, mask_of.leak, mask_of.ptr, mask_of.ld)
+    return _lib.epilogue(bias, act, leak)
+
+
+def _ensure_premasked(g, t):
+    """Make t's gradient buffer hold dL/d(pre-activation) if t is an activation output."""
+    if t.act != ACT_NONE and not t.grad_masked:
+        g.lib.act_bwd(t.rows, t.C, t.grad_ptr, t.ld, t.ptr, t.ld, t.grad_ptr, t.ld, t.act, t.leak, g.stream)
+        t.grad_masked = True
+
+
+def _note_grad_written(x, masked):
+    x.grad_written = True
+    x.grad_masked = masked
+
+
+class ConvNode(Node):
+    """conv2d_msra (tf_utils.py:70-84) / deconv2d_msra (tf_utils.py:87-98) with the following
+    lrelu/relu/tanh fused into the epilogue."""
+
+    def __init__(self, x, y, w, b, kh, kw, sh, sw, transposed):
+        self.x, self.y, self.w, self.b = x, y, w, b
+        self.k = (kh, kw, sh, sw)
+        self.transposed = transposed
+        self.act, self.leak = ACT_NONE, 0.2
+
+    def geom(self):
+        kh, kw, sh, sw = self.k
+        img, feat = (self.y, self.x) if self.transposed else (self.x, self.y)
+        n, h, w, c = img.shape
+        return _lib.conv_geom(n, h, w, c, feat.shape[3], kh, kw, sh, sw, img.ld, feat.ld)
+
+    def workspace_bytes(self, g):
+        return g.lib.conv_workspace_bytes(C.byref(self.geom()))
+
+    def forward(self, g):
+        geom = self.geom()
+        epi = _epi(self.b.ptr if self.b is not None else None, self.act, self.leak)
+        fn = g.lib.deconv2d_fwd if self.transposed else g.lib.conv2d_fwd
+        fn(C.byref(geom), self.x.ptr, self.w.ptr, self.y.ptr, C.byref(epi), g.ws_ptr, g.ws_bytes, g.stream)
+
+    def backward(self, g):
+        y, x = self.y, self.x
+        if not y.grad_written:
+            return
+        _ensure_premasked(g, y)
+        geom = self.geom()
+        if self.transposed:
+            g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, g.ws_ptr, g.ws_bytes, g.stream)
+        else:
+            g.lib.conv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr,
+                               self.b.grad_ptr if self.b is not None else None, g.ws_ptr, g.ws_bytes, g.stream)
+        self.w.has_grad = True
+        if self.b is not None:
+            self.b.has_grad = True
+        if x.requires_grad:
+            epi = _epi(mask_of=x)
+            fn = g.lib.deconv2d_dgrad if self.transposed else g.lib.conv2d_dgrad
+            fn(C.byref(geom), y.grad_ptr, self.w.ptr, x.grad_ptr, C.byref(epi), g.ws_ptr, g.ws_bytes, g.stream)
+            _note_grad_written(x, x.act != ACT_NONE)
+
+
+class LinearNode(Node):
+    """linear_msra (tf_utils.py:54-67)."""
+
+    def __init__(self, x, y, m, b):
+        self.x, self.y, self.m, self.b = x, y, m, b
+        self.act, self.leak = ACT_NONE, 0.2
+
+    def workspace_bytes(self, g):
+        return g.lib.fc_workspace_bytes(self.x.shape[0], self.x.C, self.y.C)
+
+    def forward(self, g):
+        x, y = self.x, self.y
+        epi = _epi(self.b.ptr, self.act, self.leak)
+        g.lib.fc_fwd(x.shape[0], x.C, y.C, x.ptr, x.ld, self.m.ptr, y.ptr, y.ld, C.byref(epi), g.ws_ptr, g.ws_bytes, g.stream)
+
+    def backward(self, g):
+        x, y = self.x, self.y
+        if not y.grad_written:
+            return
+        _ensure_premasked(g, y)
+        g.lib.fc_wgrad(x.shape[0], x.C, y.C, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
+                       g.ws_ptr, g.ws_bytes, g.stream)
+        self.m.has_grad = self.b.has_grad = True
+        if x.requires_grad:
+            epi = _epi(mask_of=x)
+            g.lib.fc_dgrad(x.shape[0], x.C, y.C, y.grad_ptr, y.ld, self.m.ptr, x.grad_ptr, x.ld, C.byref(epi),
+                           g.ws_ptr, g.ws_bytes, g.stream)
+            _note_grad_written(x, x.act != ACT_NONE)
+
+
+class ActNode(Node):
+    """Stand-alone activation (only when it could not be fused into its producer)."""
+
+    def __init__(self, x, y, act, leak):
+        self.x, self.y, self.act, self.leak = x, y, act, leak
+
+    def forward(self, g):
+        x, y = self.x, self.y
+        g.lib.act_fwd(x.rows, x.C, x.ptr, x.ld, y.ptr, y.ld, self.act, self.leak, g.stream)
+
+    def backward(self, g):
+        x, y = self.x, self.y
+        if not y.grad_written or not x.requires_grad:
+            return
+        _ensure_premasked(g, y)          # y.grad now holds dL/dx
+        g.lib.copy2d(x.rows, x.C, y.grad_ptr, y.ld, 1, x.grad_ptr, x.ld, 0, g.stream)
+        _note_grad_written(x, False)
+
+
+class ViewNode(Node):
+    """tf.reshape / tf.split / zero-copy tf.concat: no kernels; only gradient bookkeeping."""
+
+    def __init__(self, ins, outs):
+        self.ins, self.outs = ins, outs
+
+    def forward(self, g):
+        pass
+
+    def backward(self, g):
+        written = [o for o in self.outs if o.grad_written]
+        if not written:
+            return
+        if len(written) != len(self.outs):
+            # a slice nobody differentiated through: its gradient is zero
+            for o in self.outs:
+                if not o.grad_written and o.requires_grad:
+                    g.lib.copy2d(o.rows, o.C, g.zero_ptr, 0, max(o.rows, 1) * 4, o.grad_ptr, o.ld, 0, g.stream)
+                    _note_grad_written(o, o.act != ACT_NONE)
+        masked = [o.grad_masked for o in self.outs if o.requires_grad]
+        want_mask = any(masked)
+        if want_mask and not all(masked):
+            for o in self.outs:
+                if o.requires_grad:
+                    _ensure_premasked(g, o)
+        for i in self.ins:
+            if i.requires_grad:
+                if want_mask and i.act == ACT_NONE:
+                    raise RuntimeError("view of mixed activation / linear tensors cannot carry a masked gradient")
+                _note_grad_written(i, want_mask)
+
+
+class CopyConcatNode(Node):
+    """tf.concat fallback when an input cannot be adopted as a slice (copies)."""
+
+    def __init__(self, ins, out):
+        self.ins, self.out = ins, out
+
+    def forward(self, g):
+        off = 0
+        for t in self.ins:
+            g.lib.copy2d(t.rows, t.C, t.ptr, t.ld, 1, self.out.ptr + 4 * off, self.out.ld, 0, g.stream)
+            off += t.C
+
+    def backward(self, g):
+        o = self.out
+        if not o.grad_written:
+            return
+        off = 0
+        for t in self.ins:
+            if t.requires_grad:
+                g.lib.copy2d(t.rows, t.C, o.grad_ptr + 4 * off, o.ld, 1, t.grad_ptr, t.ld, 0, g.stream)
+                _note_grad_written(t, o.grad_masked and t.act != ACT_NONE)
+                if o.grad_masked and t.act == ACT_NONE:
+                    raise RuntimeError("masked gradient reached a linear tensor through concat")
+            off += t.C
+
+
+class TileNode(Node):
+    """tf.tile of a [B,1,1,C] code over [B,h,w,C] (multiobject_appflow.py:148-149)."""
+
+    def __init__(self, x, y, reps):
+        self.x, self.y, self.reps = x, y, reps
+
+    def forward(self, g):
+        x, y = self.x, self.y
+        g.lib.copy2d(y.rows, y.C, x.ptr, x.ld, self.reps, y.ptr, y.ld, 0, g.stream)
+
+    def backward(self, g):
+        x, y = self.x, self.y
+        if not y.grad_written or not x.requires_grad:
+            return
+        g.lib.group_sum(x.rows, self.reps, x.C, y.grad_ptr, y.ld, x.grad_ptr, x.ld, g.stream)
+        _note_grad_written(x, y.grad_masked)
+
+
+class ResampleNode(Node):
+    """warp_pts_layer + resample_layer (tf_utils.py:35-42) fused: flow -> (warp_pts, gen)."""
+
+    def __init__(self, src, flow, warp, gen):
+        self.src, self.flow, self.warp, self.gen = src, flow, warp, gen
+
+    def forward(self, g):
+        n, h, w, _ = self.flow.shape
+        _, hs, ws, c = self.src.shape
+        g.lib.warp_resample_fwd(n, h, w, hs, ws, c, self.src.ptr, self.flow.ptr, self.flow.ld,
+                                self.warp.ptr, self.gen.ptr, g.stream)
+
+    def backward(self, g):
+        if not self.gen.grad_written or not self.flow.requires_grad:
+            return
+        n, h, w, _ = self.flow.shape
+        _, hs, ws, c = self.src.shape
+        g.lib.warp_resample_bwd(n, h, w, hs, ws, c, self.src.ptr, self.flow.ptr, self.flow.ld,
+                                self.gen.grad_ptr, self.flow.grad_ptr, self.flow.ld, g.stream)
+        _note_grad_written(self.flow, False)
+
+
+# =============================================================================================== graph
+class Graph:
+    """Build with the tf_utils functions inside `with Graph(...)`, then finalize() + compile()."""
+
+    ALIGN = 64          # variables start on 256-byte boundaries of the flat buffer
+
+    def __init__(self, device=None, seed=1234):
+        self.device = torch.device(device if device is not None else 'cuda')
+        self.rng = np.random.default_rng(seed)
+        self.nodes = []
+        self.tensors = []
+        self.inputs = OrderedDict()
+        self.variables = OrderedDict()
+        self._scope = []
+        self.loss_expr = None
+        self.lr = None
+        self.finalized = False
+        self.lib = None
+        self.stream = None
+        self.ws = None
+        self.ws_ptr, self.ws_bytes = None, 0
+        self.plan_fwd = self.plan_bwd = None
+        self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
+        self.beta1_power = np.float32(self.beta1)
+        self.beta2_power = np.float32(self.beta2)
+        self.world_size, self.dist_group = 1, None
+
+    def __enter__(self):
+        _current.append(self)
+        return self
+
+    def __exit__(self, *a):
+        _current.pop()
+
+    # ---------------------------------------------------------------- construction helpers
+    def scope_name(self, name):
+        return '/'.join(self._scope + [name])
+
+    def variable(self, name, shape, init):
+        full = self.scope_name(name)
+        if full in self.variables:
+            raise ValueError("variable %s already exists" % full)
+        v = Variable(full, shape, init)
+        v.graph = self
+        self.variables[full] = v
+        return v
+
+    def placeholder(self, shape, name):
+        t = Tensor(self, shape, name=name)
+        t.storage.external = True
+        self.inputs[name] = t
+        self.tensors.append(t)
+        return t
+
+    def new_tensor(self, shape, **kw):
+        t = Tensor(self, shape, **kw)
+        self.tensors.append(t)
+        return t
+
+    def add(self, node):
+        self.nodes.append(node)
+        return node
+
+    # ---------------------------------------------------------------- memory layout
+    def finalize(self):
+        if self.finalized:
+            return
+        self.lib = _lib.lib()
+        dev = self.device
+        roots = []
+        for t in self.tensors:
+            s = t.storage
+            base = s.alias_of if s.alias_of is not None else s
+            root, _ = base.resolve()
+            if s.needs_grad:
+                root.needs_grad = True
+            if root not in roots:
+                roots.append(root)
+        act_bytes = 0
+        for r in roots:
+            r.data = torch.zeros(r.rows * r.ch, dtype=torch.float32, device=dev)
+            act_bytes += r.rows * r.ch * 4
+            if r.needs_grad:
+                r.grad = torch.zeros(r.rows * r.ch, dtype=torch.float32, device=dev)
+                act_bytes += r.rows * r.ch * 4
+        self.activation_bytes = act_bytes
+        # variables: flat buffer in creation order (= TF trainable_variables order)
+        off = 0
+        for v in self.variables.values():
+            v.offset = off
+            off += -(-v.size // self.ALIGN) * self.ALIGN
+        self.flat_size = off
+        host = np.zeros(off, dtype=np.float32)
+        for v in self.variables.values():
+            host[v.offset:v.offset + v.size] = v.init(self.rng, v.shape).reshape(-1)
+        self.params = torch.from_numpy(host).to(dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.loss_buf = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.zero_buf = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.zero_ptr = self.zero_buf.data_ptr()
+        self.finalized = True       # pointers are valid from here on (workspace queries need them)
+        need = 0
+        for n in self.nodes:
+            if hasattr(n, 'workspace_bytes'):
+                need = max(need, int(n.workspace_bytes(self)))
+        self.ws_bytes = need
+        self.ws = torch.empty(max(need // 4, 4), dtype=torch.float32, device=dev)
+        self.ws_ptr = self.ws.data_ptr()
+
+    # ---------------------------------------------------------------- plans
+    def _emit_losses(self, with_grad):
+        self.lib.fill(self.loss_buf.data_ptr(), 1, 0.0, self.stream)
+        if self.loss_expr is None:
+            return
+        for w, term in self.loss_expr.terms:
+            a = term.a
+            if a.ld != a.C or term.b.ld != term.b.C:
+                raise NotImplementedError("loss on a channel-sliced tensor")
+            grad = a.grad_ptr if (with_grad and a.requires_grad) else None
+            self.lib.pixel_loss(a.rows, a.C, a.ptr, term.b.ptr, term.mask.ptr if term.mask is not None else None,
+                                term.kind, float(w), self.loss_buf.data_ptr(), grad, self.stream)
+            if grad is not None:
+                _note_grad_written(a, False)
+
+    def compile(self, stream=None):
+        """Record the forward (+loss, +loss gradient) and backward launch sequences."""
+        self.finalize()
+        self.stream = stream        # None = the null stream; plans take the stream at run time
+        lib = self.lib
+        for t in self.tensors:
+            t.grad_written = t.grad_masked = False
+        self.plan_fwd = lib.plan_create()
+        lib.plan_begin(self.plan_fwd)
+        try:
+            for n in self.nodes:
+                n.forward(self)
+            self._emit_losses(with_grad=True)
+        finally:
+            lib.plan_end()
+        self.plan_bwd = lib.plan_create()
+        lib.plan_begin(self.plan_bwd)
+        try:
+            for n in reversed(self.nodes):
+                n.backward(self)
+        finally:
+            lib.plan_end()
+        # Adam runs over the prefix of the flat buffer that holds variables with a gradient path;
+        # variables without one (highdim_angle.py:8-9) keep zero gradients and are never touched.
+        self.n_launch_fwd = lib.plan_size(self.plan_fwd)
+        self.n_launch_bwd = lib.plan_size(self.plan_bwd)
+        return self
+
+    # ---------------------------------------------------------------- execution
+    def _stream_ptr(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def run_forward(self):
+        self.lib.plan_run(self.plan_fwd, self._stream_ptr())
+
+    def run_backward(self):
+        self.lib.plan_run(self.plan_bwd, self._stream_ptr())
+
+    def allreduce_grads(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.dist_group)
+
+    def apply_adam(self):
+        self.lib.adam_step(self.flat_size, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                           self.adam_v.data_ptr(), float(self.lr), self.beta1, self.beta2, self.eps,
+                           float(self.beta1_power), float(self.beta2_power), 1.0 / self.world_size, self._stream_ptr())
+        self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
+        self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
+
+    def train_step(self):
+        """forward + loss + reverse pass + (all-reduce) + Adam; returns the device loss scalar."""
+        self.run_forward()
+        self.run_backward()
+        self.allreduce_grads()
+        self.apply_adam()
+        return self.loss_buf[0]
+
+    # ---------------------------------------------------------------- variables I/O
+    def get_variables(self):
+        return OrderedDict((k, v.value().detach().cpu().numpy().copy()) for k, v in self.variables.items())
+
+    def set_variables(self, values):
+        for k, a in values.items():
+            self.variables[k].value().copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)).reshape(self.variables[k].shape))
+
+    def get_gradients(self):
+        return OrderedDict((k, v.grad_value().detach().cpu().numpy().copy()) for k, v in self.variables.items() if v.has_grad)
+
+    def state_dict(self):
+        """TF-Saver-style names: <var>, <var>/Adam, <var>/Adam_1, beta1_power, beta2_power
+        (train.py:70-71 saves GLOBAL_VARIABLES)."""
+        sd = OrderedDict()
+        for k, v in self.variables.items():
+            sd[k] = v.value().detach().cpu().clone()
+            if v.has_grad:
+                sd[k + '/Adam'] = self.adam_m[v.offset:v.offset + v.size].view(v.shape).detach().cpu().clone()
+                sd[k + '/Adam_1'] = self.adam_v[v.offset:v.offset + v.size].view(v.shape).detach().cpu().clone()
+        sd['beta1_power'] = torch.tensor(float(self.beta1_power))
+        sd['beta2_power'] = torch.tensor(float(self.beta2_power))
+        return sd
+
+    def load_state_dict(self, sd):
+        for k, v in self.variables.items():
+            v.value().copy_(sd[k])
+            if k + '/Adam' in sd:
+                self.adam_m[v.offset:v.offset + v.size].view(v.shape).copy_(sd[k + '/Adam'])
+                self.adam_v[v.offset:v.offset + v.size].view(v.shape).copy_(sd[k + '/Adam_1'])
+        self.beta1_power = np.float32(float(sd['beta1_power']))
+        self.beta2_power = np.float32(float(sd['beta2_power']))
+
+
+# =============================================================================================== initialisers
+def truncated_normal_init(stddev):
+    """tf.truncated_normal_initializer(stddev) (tf_utils.py:77): redraw beyond 2 sigma."""
+    def init(rng, shape):
+        out = rng.standard_normal(shape)
+        bad = np.abs(out) > 2
+        while bad.any():
+            out[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(out) > 2
+        return (out * stddev).astype(np.float32)
+    return init
+
+
+def random_normal_init(stddev):
+    """tf.random_normal_initializer(stddev) (tf_utils.py:63,95)."""
+    return lambda rng, shape: (rng.standard_normal(shape) * stddev).astype(np.float32)
+
+
+def zeros_init():
+    """tf.constant_initializer(0.) (tf_utils.py:65,80)."""
+    return lambda rng, shape: np.zeros(shape, np.float32)

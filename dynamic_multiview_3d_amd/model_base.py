@@ -1,0 +1,88 @@
+"""Shared machinery of the model classes: graph ownership, feeding, stepping, checkpoints.
+
+The reference classes own a TF graph + placeholders and are driven by
+sess.run([model.loss, model.train_op], {model.train_cond: 1}) (multi_view_model/train.py:120-123).
+Here `train_step(**feeds)` / `forward(**feeds)` are the explicit replacements of those
+sess.run calls; everything else keeps the reference attribute names.
+"""
+import os
+import re
+
+import torch
+
+from .graph import Graph
+
+
+class Saver:
+    """tf.train.Saver stand-in (train.py:70-71,134-136): variables + Adam slots under TF names."""
+
+    def __init__(self, graph):
+        self.graph = graph
+
+    def save(self, sess, path):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(self.graph.state_dict(), path)
+        return path
+
+    def restore(self, sess, path):
+        self.graph.load_state_dict(torch.load(path, map_location='cpu'))
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer(lr).minimize(loss) (appearance_flow_model.py:77): TF defaults
+    beta1=0.9, beta2=0.999, epsilon=1e-8; the update itself is mv3d_adam_step."""
+
+    def __init__(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.lr, self.beta1, self.beta2, self.eps = learning_rate, beta1, beta2, epsilon
+
+    def minimize(self, loss, graph):
+        graph.loss_expr = loss
+        graph.lr = self.lr
+        graph.beta1, graph.beta2, graph.eps = self.beta1, self.beta2, self.eps
+        return 'train_op'
+
+
+class ModelBase(object):
+    input_names = ()
+
+    def _make_graph(self, device, seed):
+        self.graph = Graph(device=device, seed=seed)
+        return self.graph
+
+    def _finish(self, build_loss):
+        self.t_vars = list(self.graph.variables.keys())
+        self.saver = Saver(self.graph)
+        self.graph.compile()
+
+    # ---- sess.run replacements
+    def feed(self, **feeds):
+        for k, v in feeds.items():
+            if v is None:
+                continue
+            if k not in self.graph.inputs:
+                raise KeyError("unknown input %r (have %s)" % (k, list(self.graph.inputs)))
+            self.graph.inputs[k].set(v)
+
+    def train_step(self, **feeds):
+        """One sess.run([model.loss, model.train_op], {train_cond: 1}); returns the loss as a
+        0-d device tensor (call float() on it to synchronise)."""
+        if self.graph.loss_expr is None:
+            raise RuntimeError("model was built with build_loss=False")
+        self.feed(**feeds)
+        return self.graph.train_step()
+
+    def forward(self, **feeds):
+        """One forward pass (the train_cond: 0 / visualize path, train.py:130, appearance_flow_model.py:134)."""
+        self.feed(**feeds)
+        self.graph.run_forward()
+        return self.graph.loss_buf[0]
+
+    # ---- data-parallel hook
+    def enable_data_parallel(self, world_size, group=None):
+        self.graph.world_size = int(world_size)
+        self.graph.dist_group = group
+
+
+def iteration_from_checkpoint_name(path):
+    """train.py:99-101: resume iteration = trailing digits of the checkpoint file name."""
+    return int(re.match('.*?([0-9]+)$', path).group(1))

@@ -1,0 +1,158 @@
+/* mv3d_hip.h -- C ABI of libmv3d_hip.so: the MI355X (gfx950) kernels behind the
+ * appearance-flow train step of aclike/dynamic_multiview_3d.
+ *
+ * The reference has no native code: every entry point below replaces one TensorFlow-1.3
+ * op call site of dyn_mult_view/mv3d/utils/tf_utils.py (cited per function) plus the
+ * reverse-mode ops tf.train.AdamOptimizer.minimize() derives from it
+ * (multi_view_model/appearance_flow_model.py:77).
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch/HIP types: a stream is passed as void* (hipStream_t).
+ *  - every pointer is DEVICE memory owned by the caller; the library never allocates or
+ *    frees device memory and keeps no global mutable state (except an optional recording plan,
+ *    see mv3d_plan_*).  Scratch is passed in as (workspace, workspace_bytes).
+ *  - all calls are asynchronous on `stream` and return 0 (MV3D_OK) or a negative MV3D_E_*;
+ *    shape/alignment violations are rejected BEFORE anything is launched.
+ *    mv3d_last_error() returns a thread-local message for the last failure.
+ *  - activations are NHWC; a tensor may be a channel slice of a wider buffer: `*_ld` is the
+ *    element stride between consecutive pixels (>= channels).  This makes tf.concat /
+ *    tf.split on the channel axis free (main_model.py:94,131).
+ *  - conv filters HWIO [kh,kw,Cin,Cout] (tf_utils.py:76), deconv filters [kh,kw,Cout,Cin]
+ *    (tf_utils.py:94), fc matrices [in,out] (tf_utils.py:61).  Both filter kinds are
+ *    [kh,kw,C_image_side,C_feature_side].
+ *  - dtype: MV3D_F32 only in this round (IEEE fp32 in/out, fp32 MFMA accumulate).
+ */
+#ifndef MV3D_HIP_H
+#define MV3D_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MV3D_OK = 0, MV3D_E_INVAL = -1, MV3D_E_HIP = -2, MV3D_E_WORKSPACE = -3, MV3D_E_UNSUPPORTED = -4 };
+enum { MV3D_F32 = 0 };
+/* activation kinds: value = f1*x + f2*|x| forms of tf_utils.py:25-33, tf.nn.tanh (main_model.py:79) */
+enum { MV3D_ACT_NONE = 0, MV3D_ACT_LRELU = 1, MV3D_ACT_RELU = 2, MV3D_ACT_TANH = 3 };
+
+/* Geometry of one conv2d / conv2d_transpose layer.  The IMAGE side is the strided-into tensor
+ * (conv input, deconv output); the FEATURE side is the other one (conv output, deconv input):
+ * Ho = ceil(H/sh), Wo = ceil(W/sw), TF 'SAME' padding (pad_before = total/2). */
+typedef struct mv3d_conv_geom {
+    int32_t N;              /* batch */
+    int32_t H, W, C;        /* image side  */
+    int32_t Ho, Wo, K;      /* feature side */
+    int32_t kh, kw, sh, sw;
+    int32_t img_ld, feat_ld;/* pixel strides (elements) of the image-/feature-side tensors */
+    int32_t dtype;          /* MV3D_F32 */
+} mv3d_conv_geom;
+
+/* Fused epilogue applied to the tensor a kernel produces.
+ *   y = act(acc + bias)                  (forward: tf_utils.py:82 '+ b', :25-33 activations)
+ *   y = acc * act'(ref)                  (backward: the producing layer's activation gradient,
+ *                                         evaluated from its saved OUTPUT `ref`; TF: sign(0)=0)
+ * gmask_ref has the shape of the produced tensor, pixel stride gmask_ld. */
+typedef struct mv3d_epilogue {
+    const void* bias;       /* [channels] or NULL */
+    int32_t act;            /* MV3D_ACT_* applied to the result */
+    float leak;             /* lrelu leak (tf_utils.py:29: 0.2) */
+    int32_t gmask_act;      /* MV3D_ACT_* whose derivative multiplies the result, or NONE */
+    float gmask_leak;
+    const void* gmask_ref;
+    int32_t gmask_ld;
+} mv3d_epilogue;
+
+const char* mv3d_version(void);
+const char* mv3d_last_error(void);
+
+/* ---- conv2d: tf.nn.conv2d(x, w, [1,sh,sw,1], 'SAME') + b  (tf_utils.py:81-82) ------------- */
+/* y[N,Ho,Wo,K] = epi( x[N,H,W,C] (*) w[kh,kw,C,K] ) */
+int mv3d_conv2d_fwd(const mv3d_conv_geom* g, const void* x, const void* w, void* y,
+                    const mv3d_epilogue* epi, void* workspace, size_t workspace_bytes, void* stream);
+/* dx[N,H,W,C] = epi( Conv2DBackpropInput(dy[N,Ho,Wo,K], w) ) */
+int mv3d_conv2d_dgrad(const mv3d_conv_geom* g, const void* dy, const void* w, void* dx,
+                      const mv3d_epilogue* epi, void* workspace, size_t workspace_bytes, void* stream);
+/* dw[kh,kw,C,K] = Conv2DBackpropFilter(x, dy);  db[K] = BiasAddGrad(dy) (db may be NULL) */
+int mv3d_conv2d_wgrad(const mv3d_conv_geom* g, const void* x, const void* dy, void* dw, void* db,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- conv2d_transpose: tf.nn.conv2d_transpose(x, w, output_shape, strides) (tf_utils.py:96-97)
+ * x is the FEATURE side [N,Ho,Wo,K], y the IMAGE side [N,H,W,C], w [kh,kw,C,K]; no bias in the
+ * reference (epi->bias must be NULL unless the caller wants one). */
+int mv3d_deconv2d_fwd(const mv3d_conv_geom* g, const void* x, const void* w, void* y,
+                      const mv3d_epilogue* epi, void* workspace, size_t workspace_bytes, void* stream);
+int mv3d_deconv2d_dgrad(const mv3d_conv_geom* g, const void* dy, const void* w, void* dx,
+                        const mv3d_epilogue* epi, void* workspace, size_t workspace_bytes, void* stream);
+int mv3d_deconv2d_wgrad(const mv3d_conv_geom* g, const void* x, const void* dy, void* dw,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* bytes of scratch the six calls above may need for this geometry (max over them) */
+size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g);
+
+/* ---- linear: tf.matmul(x, M) + b  (tf_utils.py:67) ------------------------------------------
+ * x [B,in] (row stride x_ld), M [in,out] dense, y [B,out] (row stride y_ld). */
+int mv3d_fc_fwd(int B, int in, int out, const void* x, int x_ld, const void* M, void* y, int y_ld,
+                const mv3d_epilogue* epi, void* workspace, size_t workspace_bytes, void* stream);
+int mv3d_fc_dgrad(int B, int in, int out, const void* dy, int dy_ld, const void* M, void* dx, int dx_ld,
+                  const mv3d_epilogue* epi, void* workspace, size_t workspace_bytes, void* stream);
+int mv3d_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld,
+                  void* dM, void* db, void* workspace, size_t workspace_bytes, void* stream);
+size_t mv3d_fc_workspace_bytes(int B, int in, int out);
+
+/* ---- element-wise pieces -------------------------------------------------------------------- */
+/* y = act(x) on [rows, ch] with row strides (standalone form of tf_utils.py:25-33 / tanh) */
+int mv3d_act_fwd(int64_t rows, int ch, const void* x, int x_ld, void* y, int y_ld, int act, float leak, void* stream);
+/* dx = dy * act'(ref) with ref = the activation's OUTPUT (sign(0) = 0) */
+int mv3d_act_bwd(int64_t rows, int ch, const void* dy, int dy_ld, const void* ref, int ref_ld,
+                 void* dx, int dx_ld, int act, float leak, void* stream);
+/* strided copy / accumulate of [rows, ch] blocks (tf.concat/tf.split glue that cannot be a view,
+ * tf.tile of the angle code over 4x4: multiobject_appflow.py:148-150):
+ * dst[r*dst_ld + c] (+)= src[(r / src_row_div) * src_ld + c] */
+int mv3d_copy2d(int64_t rows, int ch, const void* src, int64_t src_ld, int64_t src_row_div,
+                void* dst, int64_t dst_ld, int accumulate, void* stream);
+/* dst[g, c] = sum_{r < group} src[(g*group + r)*src_ld + c]   (gradient of the tile above) */
+int mv3d_group_sum(int64_t groups, int group, int ch, const void* src, int64_t src_ld, void* dst, int64_t dst_ld, void* stream);
+
+/* ---- warp + resampler: warp_pts_layer + resample_layer (tf_utils.py:35-52) ------------------
+ * flow [N,H,W,2] (pixel stride flow_ld); warp = flow + coords where coords[...,0] = ROW index,
+ * coords[...,1] = COLUMN index (tf_utils.py:48-51) and tf.contrib.resampler reads warp[...,0]
+ * as x (column) and warp[...,1] as y (row); zero outside.
+ * src [N,Hs,Ws,C] dense.  gen [N,H,W,C] dense.  warp_out (optional) [N,H,W,2] dense. */
+int mv3d_warp_resample_fwd(int N, int H, int W, int Hs, int Ws, int C, const void* src, const void* flow, int flow_ld,
+                           void* warp_out, void* gen, void* stream);
+/* dflow[N,H,W,2] (pixel stride dflow_ld) = resampler grad w.r.t. warp (= grad w.r.t. flow) */
+int mv3d_warp_resample_bwd(int N, int H, int W, int Hs, int Ws, int C, const void* src, const void* flow, int flow_ld,
+                           const void* dgen, void* dflow, int dflow_ld, void* stream);
+
+/* ---- losses: euclidean_loss / l1_loss (tf_utils.py:18-23) -----------------------------------
+ * loss_accum[0] += weight * mean_{n,h,w} sum_c f((a-b)*mask);  grad (optional, same shape as a,
+ * dense) = d(weight*loss)/da.  kind 2 = squared (euclidean), 1 = absolute (l1).  mask (optional)
+ * is [pixels,1] and multiplies the difference (multiobject_appflow.py:239-242).
+ * loss_accum must be zeroed by the caller before the first term (mv3d_fill). */
+int mv3d_pixel_loss(int64_t pixels, int ch, const void* a, const void* b, const void* mask, int kind, float weight,
+                    void* loss_accum, void* grad, void* stream);
+int mv3d_fill(void* dst, int64_t count, float value, void* stream);
+
+/* ---- Adam: tf.train.AdamOptimizer ApplyAdam (appearance_flow_model.py:77) -------
+ *   alpha = lr*sqrt(1-beta2_power)/(1-beta1_power);  m += (g-m)(1-b1);  v += (g*g-v)(1-b2);
+ *   p -= m*alpha/(sqrt(v)+eps).   One fused pass over a flat fp32 buffer; grad_scale multiplies g
+ *   first (1/world_size after a SUM all-reduce). */
+int mv3d_adam_step(int64_t count, void* p, const void* g, void* m, void* v, float lr, float beta1, float beta2,
+                   float eps, float beta1_power, float beta2_power, float grad_scale, void* stream);
+
+/* ---- recorded plans: native replay of a fixed launch sequence (the step is static) ----------
+ * Between mv3d_plan_begin() and mv3d_plan_end() every mv3d_* op call on this thread is RECORDED
+ * (validated, not launched).  mv3d_plan_run() launches the recorded sequence on a stream in one
+ * native call (no per-op Python/ctypes cost); it is capture-safe (hipGraph). */
+typedef struct mv3d_plan mv3d_plan;
+mv3d_plan* mv3d_plan_create(void);
+void mv3d_plan_destroy(mv3d_plan* p);
+int mv3d_plan_begin(mv3d_plan* p);
+int mv3d_plan_end(void);
+int mv3d_plan_size(const mv3d_plan* p);
+int mv3d_plan_run(const mv3d_plan* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,305 @@
+"""Parity of every HIP entry point (through the C ABI) against the numpy oracle.
+Tolerances: fp32 MFMA accumulates a k-ordered fma chain, numpy's BLAS blocks differently, so
+element-wise agreement is ~1e-6 relative to the tensor's max; the bar here is 2e-5 (north_star
+asks for 1e-3).  Index/byte work (resampler validity, zero-flow transpose) is exact."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+from dynamic_multiview_3d_amd import _lib
+from tests.gpu_utils import dev, host, stream, Ws, rel_err, conv_ws
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+RNG = np.random.default_rng(11)
+
+
+def L():
+    return _lib.lib()
+
+
+CONV_CASES = [  # n, h, w, c, k, ksz, s
+    (2, 128, 128, 3, 32, 5, 2),      # e0 (folded small-C path)
+    (2, 64, 64, 32, 32, 5, 1),       # e0_0 / d1_0
+    (2, 64, 64, 32, 32, 5, 2),       # e1
+    (3, 32, 32, 32, 64, 5, 2),       # e2
+    (2, 16, 16, 64, 64, 5, 1),       # e2_0 / d3_0
+    (2, 16, 16, 64, 128, 3, 2),      # e3
+    (4, 8, 8, 128, 128, 3, 1),       # e3_0 / d4_0
+    (4, 8, 8, 128, 256, 3, 2),       # e4
+    (8, 4, 4, 256, 256, 3, 1),       # e4_0
+    (1, 7, 9, 5, 20, 3, 2),          # ragged: odd sizes, channels not multiples of 4
+    (2, 128, 128, 1, 32, 5, 2),      # depth / mask tower e0
+    (2, 128, 128, 3, 16, 3, 2),      # tinghui e0
+    (1, 16, 16, 128, 64, 5, 1),      # d3_0 with 2 decoders (Cout 128 -> here reversed sizes)
+    (2, 4, 4, 320, 256, 3, 1),       # fully_conv e4_1 (256+64 in)
+    (1, 5, 5, 8, 8, 1, 1),           # 1x1
+]
+
+
+@pytest.mark.parametrize("n,h,w,c,k,ksz,s", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(n, h, w, c, k, ksz, s):
+    x = RNG.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (RNG.standard_normal((ksz, ksz, c, k)) / np.sqrt(ksz * ksz * c)).astype(np.float32)
+    b = RNG.standard_normal(k).astype(np.float32)
+    g = _lib.conv_geom(n, h, w, c, k, ksz, ksz, s, s)
+    ws = conv_ws(g)
+    dx_, dw_, db_ = dev(x), dev(wt), dev(b)
+    y = torch.full((n, g.Ho, g.Wo, k), float('nan'), device='cuda')
+    # forward with bias + lrelu epilogue
+    epi = _lib.epilogue(db_.data_ptr(), _lib.ACT_LRELU, 0.2)
+    L().conv2d_fwd(C.byref(g), dx_.data_ptr(), dw_.data_ptr(), y.data_ptr(), C.byref(epi), ws.ptr, ws.bytes, stream())
+    pre = ops.conv2d_fwd(x, wt, b, s, s)
+    ref = ops.absact_fwd(pre, 'lrelu')
+    assert rel_err(host(y), ref) < TOL
+    # backward pieces
+    dy = RNG.standard_normal(ref.shape).astype(np.float32)
+    rdx, rdw, rdb = ops.conv2d_bwd(x, wt, dy, s, s)
+    ddy = dev(dy)
+    gx = torch.full((n, h, w, c), float('nan'), device='cuda')
+    epi0 = _lib.epilogue()
+    L().conv2d_dgrad(C.byref(g), ddy.data_ptr(), dw_.data_ptr(), gx.data_ptr(), C.byref(epi0), ws.ptr, ws.bytes, stream())
+    assert rel_err(host(gx), rdx) < TOL
+    gw = torch.full(wt.shape, float('nan'), device='cuda')
+    gb = torch.full((k,), float('nan'), device='cuda')
+    L().conv2d_wgrad(C.byref(g), dx_.data_ptr(), ddy.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.ptr, ws.bytes, stream())
+    assert rel_err(host(gw), rdw) < TOL
+    assert rel_err(host(gb), rdb) < TOL
+
+
+DECONV_CASES = [  # n, hi, wi, cin(feature side K), cout(image side C), ksz, s
+    (8, 4, 4, 256, 128, 3, 2),       # d4
+    (4, 8, 8, 128, 64, 3, 2),        # d3
+    (2, 16, 16, 64, 32, 5, 2),       # d2
+    (2, 32, 32, 64, 32, 5, 2),       # d1
+    (2, 64, 64, 32, 2, 5, 2),        # flow_field (thin VALU path)
+    (2, 64, 64, 32, 3, 5, 2),        # rgb head
+    (2, 64, 64, 32, 1, 5, 2),        # depth / mask head
+    (2, 32, 32, 16, 2, 3, 1),        # tinghui flow head (stride 1)
+    (1, 3, 5, 8, 6, 5, 2),           # ragged
+    (2, 8, 8, 32, 128, 3, 2),        # tinghui d3
+    (1, 4, 4, 12, 5, 3, 1),          # stride-1 generic, odd channels
+]
+
+
+@pytest.mark.parametrize("n,hi,wi,ci,co,ksz,s", DECONV_CASES)
+def test_deconv2d_fwd_dgrad_wgrad(n, hi, wi, ci, co, ksz, s):
+    x = RNG.standard_normal((n, hi, wi, ci)).astype(np.float32)
+    wt = (RNG.standard_normal((ksz, ksz, co, ci)) / np.sqrt(ksz * ksz * ci)).astype(np.float32)
+    H, W = hi * s, wi * s
+    g = _lib.conv_geom(n, H, W, co, ci, ksz, ksz, s, s)
+    ws = conv_ws(g)
+    dx_, dw_ = dev(x), dev(wt)
+    y = torch.full((n, H, W, co), float('nan'), device='cuda')
+    epi = _lib.epilogue(None, _lib.ACT_TANH if co <= 3 else _lib.ACT_NONE)
+    L().deconv2d_fwd(C.byref(g), dx_.data_ptr(), dw_.data_ptr(), y.data_ptr(), C.byref(epi), ws.ptr, ws.bytes, stream())
+    ref = ops.deconv2d_fwd(x, wt, (H, W), s, s)
+    if co <= 3:
+        ref = np.tanh(ref)
+    assert rel_err(host(y), ref) < TOL
+    dy = RNG.standard_normal(ref.shape).astype(np.float32)
+    rdx, rdw = ops.deconv2d_bwd(x, wt, dy, s, s)
+    ddy = dev(dy)
+    gx = torch.full(x.shape, float('nan'), device='cuda')
+    epi0 = _lib.epilogue()
+    L().deconv2d_dgrad(C.byref(g), ddy.data_ptr(), dw_.data_ptr(), gx.data_ptr(), C.byref(epi0), ws.ptr, ws.bytes, stream())
+    assert rel_err(host(gx), rdx) < TOL
+    gw = torch.full(wt.shape, float('nan'), device='cuda')
+    L().deconv2d_wgrad(C.byref(g), dx_.data_ptr(), ddy.data_ptr(), gw.data_ptr(), ws.ptr, ws.bytes, stream())
+    assert rel_err(host(gw), rdw) < TOL
+
+
+def test_conv_channel_slices_and_gmask():
+    """Channel-slice views (tf.concat / tf.split as strides) and the fused act'(out) epilogue."""
+    n, h, w, c, k = 2, 16, 16, 32, 64
+    xbuf = RNG.standard_normal((n, h, w, 96)).astype(np.float32)      # x = channels 32..63 of a 96-wide buffer
+    x = xbuf[..., 32:64]
+    wt = (RNG.standard_normal((5, 5, c, k)) * 0.05).astype(np.float32)
+    g = _lib.conv_geom(n, h, w, c, k, 5, 5, 1, 1, img_ld=96, feat_ld=128)
+    ws = conv_ws(g)
+    dxb, dw_ = dev(xbuf), dev(wt)
+    ybuf = torch.zeros((n, h, w, 128), device='cuda')
+    epi = _lib.epilogue()
+    L().conv2d_fwd(C.byref(g), dxb.data_ptr() + 4 * 32, dw_.data_ptr(), ybuf.data_ptr() + 4 * 64, C.byref(epi), ws.ptr, ws.bytes, stream())
+    ref = ops.conv2d_fwd(x, wt, None, 1, 1)
+    yb = host(ybuf)
+    assert rel_err(yb[..., 64:], ref) < TOL
+    assert np.all(yb[..., :64] == 0)
+    # dgrad into a slice, multiplied by lrelu'(saved output) with exact zeros in the saved output
+    dy = RNG.standard_normal(ref.shape).astype(np.float32)
+    saved = RNG.standard_normal(xbuf.shape).astype(np.float32)
+    saved[:, ::3, ::2, :] = 0.0
+    ddy = dev(np.concatenate([np.zeros_like(dy), dy], -1))
+    gxb = torch.zeros((n, h, w, 96), device='cuda')
+    dsaved = dev(saved)
+    epi = _lib.epilogue(None, 0, 0.2, _lib.ACT_LRELU, 0.2, dsaved.data_ptr() + 4 * 32, 96)
+    L().conv2d_dgrad(C.byref(g), ddy.data_ptr() + 4 * 64, dw_.data_ptr(), gxb.data_ptr() + 4 * 32, C.byref(epi), ws.ptr, ws.bytes, stream())
+    rdx, _, _ = ops.conv2d_bwd(x, wt, dy, 1, 1)
+    s = saved[..., 32:64]
+    slope = np.where(s > 0, 1.0, np.where(s < 0, 0.2, 0.6)).astype(np.float32)
+    got = host(gxb)
+    assert rel_err(got[..., 32:64], rdx * slope) < TOL
+    assert np.all(got[..., :32] == 0) and np.all(got[..., 64:] == 0)
+
+
+def test_relu_signed_zero_and_grad():
+    x = np.array([[-2.0, -0.0, 0.0, 3.0, -1e-20, 1e-20, -5.5, 7.25]], dtype=np.float32)
+    dx_ = dev(x)
+    y = torch.empty_like(dx_)
+    L().act_fwd(1, 8, dx_.data_ptr(), 8, y.data_ptr(), 8, _lib.ACT_RELU, 0.2, stream())
+    yy = host(y)
+    np.testing.assert_array_equal(yy, ops.absact_fwd(x, 'relu'))        # -0.0 == 0.0
+    dy = dev(np.ones_like(x))
+    gx = torch.empty_like(dx_)
+    L().act_bwd(1, 8, dy.data_ptr(), 8, y.data_ptr(), 8, gx.data_ptr(), 8, _lib.ACT_RELU, 0.2, stream())
+    np.testing.assert_array_equal(host(gx), ops.absact_bwd(x, np.ones_like(x), 'relu'))
+    for act, name in ((_lib.ACT_LRELU, 'lrelu'),):
+        L().act_fwd(1, 8, dx_.data_ptr(), 8, y.data_ptr(), 8, act, 0.2, stream())
+        np.testing.assert_array_equal(host(y), ops.absact_fwd(x, name))
+        L().act_bwd(1, 8, dy.data_ptr(), 8, y.data_ptr(), 8, gx.data_ptr(), 8, act, 0.2, stream())
+        np.testing.assert_allclose(host(gx), ops.absact_bwd(x, np.ones_like(x), name), rtol=1e-7)
+
+
+FC_CASES = [(8, 200, 96), (64, 4160, 512), (2, 2, 64), (64, 4096, 4096), (5, 64, 19)]
+
+
+@pytest.mark.parametrize("B,fin,fout", FC_CASES)
+def test_fc(B, fin, fout):
+    x = RNG.standard_normal((B, fin)).astype(np.float32)
+    m = (RNG.standard_normal((fin, fout)) / np.sqrt(fin)).astype(np.float32)
+    b = RNG.standard_normal(fout).astype(np.float32)
+    ws = Ws(int(L().fc_workspace_bytes(B, fin, fout)))
+    dx_, dm, db = dev(x), dev(m), dev(b)
+    y = torch.full((B, fout), float('nan'), device='cuda')
+    epi = _lib.epilogue(db.data_ptr(), _lib.ACT_LRELU, 0.2)
+    L().fc_fwd(B, fin, fout, dx_.data_ptr(), fin, dm.data_ptr(), y.data_ptr(), fout, C.byref(epi), ws.ptr, ws.bytes, stream())
+    ref = ops.absact_fwd(ops.linear_fwd(x, m, b), 'lrelu')
+    assert rel_err(host(y), ref) < TOL
+    dy = RNG.standard_normal(ref.shape).astype(np.float32)
+    rdx, rdm, rdb = ops.linear_bwd(x, m, dy)
+    ddy = dev(dy)
+    gx = torch.full((B, fin), float('nan'), device='cuda')
+    epi0 = _lib.epilogue()
+    L().fc_dgrad(B, fin, fout, ddy.data_ptr(), fout, dm.data_ptr(), gx.data_ptr(), fin, C.byref(epi0), ws.ptr, ws.bytes, stream())
+    assert rel_err(host(gx), rdx) < TOL
+    gm = torch.full((fin, fout), float('nan'), device='cuda')
+    gb = torch.full((fout,), float('nan'), device='cuda')
+    L().fc_wgrad(B, fin, fout, dx_.data_ptr(), fin, ddy.data_ptr(), fout, gm.data_ptr(), gb.data_ptr(), ws.ptr, ws.bytes, stream())
+    assert rel_err(host(gm), rdm) < TOL
+    assert rel_err(host(gb), rdb) < TOL
+
+
+def _resample(src, flow):
+    n, h, w, _ = flow.shape
+    _, hs, ws_, c = src.shape
+    ds, df = dev(src), dev(flow)
+    warp = torch.empty((n, h, w, 2), device='cuda')
+    gen = torch.full((n, h, w, c), float('nan'), device='cuda')
+    L().warp_resample_fwd(n, h, w, hs, ws_, c, ds.data_ptr(), df.data_ptr(), 2, warp.data_ptr(), gen.data_ptr(), stream())
+    return host(warp), host(gen), ds, df
+
+
+def test_resampler_fwd_bwd_random_and_edges():
+    n, h, c = 2, 32, 3
+    src = RNG.standard_normal((n, h, h, c)).astype(np.float32)
+    flow = RNG.uniform(-6, 6, (n, h, h, 2)).astype(np.float32)
+    flow[0, 0, :8] = 0.0                       # exactly-integer sample points
+    flow[0, 1, :4, 0] = -2.0                   # x = i - 2 -> -1 on row 1: outside (x > -1 fails)
+    flow[1, 31, :, 1] = 0.5                    # y = j + .5 -> straddles the bottom edge at j = 31
+    flow[1, 5, 5] = (40.0, -40.0)
+    warp, gen, ds, df = _resample(src, flow)
+    rwarp = ops.warp_pts_layer(flow)
+    np.testing.assert_array_equal(warp, rwarp)
+    rgen = ops.resampler_fwd(src, rwarp)
+    np.testing.assert_allclose(gen, rgen, rtol=0, atol=2e-6)
+    g = RNG.standard_normal(gen.shape).astype(np.float32)
+    dg = dev(g)
+    dflow = torch.full((n, h, h, 2), float('nan'), device='cuda')
+    L().warp_resample_bwd(n, h, h, h, h, c, ds.data_ptr(), df.data_ptr(), 2, dg.data_ptr(), dflow.data_ptr(), 2, stream())
+    _, rdw = ops.resampler_bwd(src, rwarp, g, need_ddata=False)
+    np.testing.assert_allclose(host(dflow), rdw, rtol=0, atol=2e-5)
+
+
+def test_zero_flow_is_exact_transpose():
+    """Known answer: zero flow returns the transposed source, bit-exact."""
+    src = RNG.standard_normal((3, 128, 128, 3)).astype(np.float32)
+    _, gen, _, _ = _resample(src, np.zeros((3, 128, 128, 2), np.float32))
+    np.testing.assert_array_equal(gen, src.transpose(0, 2, 1, 3))
+
+
+@pytest.mark.parametrize("kind", [2, 1])
+def test_pixel_loss(kind):
+    a = RNG.standard_normal((2, 16, 16, 3)).astype(np.float32)
+    b = RNG.standard_normal((2, 16, 16, 3)).astype(np.float32)
+    b[0, 0, 0] = a[0, 0, 0]                     # exact zeros of the difference (sign(0) = 0 for L1)
+    da, db_ = dev(a), dev(b)
+    loss = torch.zeros(4, device='cuda')
+    grad = torch.full(a.shape, float('nan'), device='cuda')
+    L().pixel_loss(2 * 16 * 16, 3, da.data_ptr(), db_.data_ptr(), None, kind, 0.5, loss.data_ptr(), grad.data_ptr(), stream())
+    if kind == 2:
+        rl, rg = ops.euclidean_loss_fwd(a, b), ops.euclidean_loss_bwd(a, b, 0.5)
+    else:
+        rl, rg = ops.l1_loss_fwd(a, b), ops.l1_loss_bwd(a, b, 0.5)
+    np.testing.assert_allclose(host(loss)[0], 0.5 * rl, rtol=2e-6)
+    np.testing.assert_allclose(host(grad), rg, rtol=1e-6, atol=1e-9)
+
+
+def test_masked_pixel_loss():
+    a = RNG.standard_normal((2, 8, 8, 3)).astype(np.float32)
+    b = RNG.standard_normal((2, 8, 8, 3)).astype(np.float32)
+    m = (RNG.uniform(size=(2, 8, 8, 1)) > 0.5).astype(np.float32)
+    loss = torch.zeros(4, device='cuda')
+    grad = torch.empty(a.shape, device='cuda')
+    L().pixel_loss(128, 3, dev(a).data_ptr(), dev(b).data_ptr(), dev(m).data_ptr(), 2, 1.0, loss.data_ptr(), grad.data_ptr(), stream())
+    d = (a - b) * m
+    np.testing.assert_allclose(host(loss)[0], (d * d).sum(3).mean(), rtol=2e-6)
+    np.testing.assert_allclose(host(grad), 2 * d * m / 128, rtol=1e-6, atol=1e-9)
+
+
+def test_adam_bit_exact_vs_oracle():
+    n = 10007
+    p = RNG.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    dp, dm, dv = dev(p), dev(m), dev(v)
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+    for t in range(4):
+        g = (RNG.standard_normal(n) * 10.0 ** RNG.integers(-6, 1)).astype(np.float32)
+        ops.adam_step(p, g, m, v, b1p, b2p, 1e-4)
+        L().adam_step(n, dp.data_ptr(), dev(g).data_ptr(), dm.data_ptr(), dv.data_ptr(), 1e-4, 0.9, 0.999, 1e-8,
+                      float(b1p), float(b2p), 1.0, stream())
+        b1p = np.float32(b1p * np.float32(0.9))
+        b2p = np.float32(b2p * np.float32(0.999))
+        np.testing.assert_array_equal(host(dm), m)
+        np.testing.assert_array_equal(host(dv), v)
+        np.testing.assert_allclose(host(dp), p, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(host(dp), p, rtol=3e-7, atol=0)
+
+
+def test_copy2d_group_sum_fill():
+    src = RNG.standard_normal((4, 6)).astype(np.float32)
+    ds = dev(src)
+    dst = torch.zeros((64, 10), device='cuda')
+    L().copy2d(64, 6, ds.data_ptr(), 6, 16, dst.data_ptr() + 4 * 2, 10, 0, stream())      # tile rows 16x into a slice
+    exp = np.zeros((64, 10), np.float32)
+    exp[:, 2:8] = np.repeat(src, 16, axis=0)
+    np.testing.assert_array_equal(host(dst), exp)
+    out = torch.zeros((4, 6), device='cuda')
+    L().group_sum(4, 16, 6, dst.data_ptr() + 4 * 2, 10, out.data_ptr(), 6, stream())
+    np.testing.assert_allclose(host(out), 16 * src, rtol=1e-6)
+    L().fill(out.data_ptr(), 24, 2.5, stream())
+    assert np.all(host(out) == 2.5)
+
+
+def test_errors_are_reported_not_launched():
+    g = _lib.conv_geom(1, 8, 8, 4, 4, 3, 3, 3, 3)            # stride 3 unsupported
+    with pytest.raises(_lib.Mv3dError, match="stride"):
+        L().conv2d_fwd(C.byref(g), 1, 1, 1, None, None, 0, None)
+    g = _lib.conv_geom(1, 8, 8, 4, 4, 3, 3, 1, 1)
+    g.Ho = 5
+    with pytest.raises(_lib.Mv3dError, match="SAME"):
+        L().conv2d_fwd(C.byref(g), 1, 1, 1, None, None, 0, None)
+    with pytest.raises(_lib.Mv3dError, match="null"):
+        L().conv2d_fwd(C.byref(_lib.conv_geom(1, 8, 8, 4, 4, 3, 3, 1, 1)), None, 1, 1, None, None, 0, None)
