@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- train images/sec of the appearance-flow model (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: forward, loss, hand-scheduled backward,
+(gradient all-reduce over RCCL when N > 1), fused TF-Adam.  Workload = BASELINE.json configs[1]
+`appflow_offset`: AppearanceFlowModel, 128x128x3, batch 64 per GPU (weak scaling), synthetic
+car-render-like batches resident in HBM before the timed region, reference initialisers.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step: algorithmic
+FLOPs of its launches (2*N*Ho*Wo*kh*kw*Cin*Cout each) over their HIP-event durations
+measured inside the timed region on the launch stream.  `cpu_baseline` times the numpy oracle
+(CPU restatement of the TF-1.3 graph; TensorFlow itself is unavailable offline) on the host
+cores, on a bounded sample (batch 8).
+"""
+import argparse
+import collections
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+TRAIN_MFLOP_PER_IMAGE_CONV = 3035.6   # BASELINE.md section 2 (fwd + dgrad + wgrad, no dgrad for e0)
+TRAIN_MFLOP_PER_IMAGE_ALL = 3440.0
+
+
+def synth_batch(rng, b, h=128):
+    """grey background, one filled ellipse, N(0,2) noise, uint8 -> /255."""
+    yy, xx = np.mgrid[0:h, 0:h]
+
+    def imgs():
+        img = np.full((b, h, h, 3), 127.0, np.float32)
+        for i in range(b):
+            cy, cx = rng.uniform(40, 88, 2) * h / 128.0
+            ay, ax = rng.uniform(15, 45, 2) * h / 128.0
+            m = ((yy - cy) / ay) ** 2 + ((xx - cx) / ax) ** 2 <= 1
+            img[i][m] = rng.uniform(0, 255, 3)
+        img += rng.normal(0, 2, img.shape).astype(np.float32)
+        return (np.clip(np.rint(img), 0, 255) / 255.0).astype(np.float32)
+    disp = np.stack([rng.uniform(-1, 1, b), rng.uniform(-6.28, 6.28, b)], 1).astype(np.float32)
+    return dict(image0=imgs(), image1=imgs(), disp=disp)
+
+
+def cpu_baseline(batch=8, steps=3):
+    """numpy oracle (oracle/: CPU restatement of the reference graph) timed on the host cores."""
+    from oracle import models as omodels
+    from oracle.graph import Tape
+    rng = np.random.default_rng(0)
+    feeds = synth_batch(rng, batch)
+    builder = omodels.appearance_flow_builder('base')
+    t = Tape(None, rng=np.random.default_rng(1234))
+    builder(t, {k: t.const(v) for k, v in feeds.items()})          # creates the variables
+    variables, adam = t.vars, omodels.AdamState(1e-4)
+    omodels.step(builder, variables, adam, feeds)                   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        omodels.step(builder, variables, adam, feeds)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": "numpy/BLAS oracle, AppearanceFlowModel fwd+bwd+Adam, %d timed steps at batch %d after 1 warm-up "
+                      "(TensorFlow 1.3 reference cannot run offline)" % (steps, batch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true', help='do not bracket launches with HIP events')
+    ap.add_argument('--dump-kernels', action='store_true', help='print the per-kernel table to stderr')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    from dynamic_multiview_3d_amd import _lib
+
+    conf = {'batch_size': args.batch, 'learning_rate': 1e-4, 'experiment_name': 'appflow_offset'}
+    model = AppearanceFlowModel(conf, load_tfrec=False, build_loss=True, device=dev, seed=1234)   # same init on all ranks
+    g = model.graph
+    model.feed(**synth_batch(np.random.default_rng(rank), args.batch))                           # resident in HBM
+    if world > 1:
+        model.enable_data_parallel(world)
+    lib = g.lib
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step()
+    timing = not args.no_kernel_timing
+    for plan in (g.plan_fwd, g.plan_bwd):
+        lib.plan_profile_reset(plan)
+        lib.plan_profile(plan, 1 if timing else 0)
+    adam_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if timing else []
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        g.run_forward()
+        g.run_backward()
+        g.allreduce_grads()
+        if timing:
+            adam_ev[i][0].record()
+        g.apply_adam()
+        if timing:
+            adam_ev[i][1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = float(g.loss_buf[0])
+
+    # ---- per-kernel accounting (rank 0's GPU)
+    kern = collections.OrderedDict()
+    if timing:
+        for plan in (g.plan_fwd, g.plan_bwd):
+            lib.plan_profile_collect(plan)
+            for name, fl, by, ms, runs in _lib.plan_ops(plan):
+                k = kern.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+                k['launches'] += 1
+                k['flops'] += fl
+                k['bytes'] += by
+                k['ms'] += ms / max(runs, 1)
+            lib.plan_profile(plan, 0)
+        adam_ms = sum(a.elapsed_time(b) for a, b in adam_ev) / len(adam_ev)
+        kern['adam'] = dict(launches=1, flops=0.0, bytes=28.0 * g.flat_size, ms=adam_ms)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+
+    out = {
+        "metric": "train images/sec, appearance-flow encoder-decoder 128x128x3 (fwd+bwd+Adam)",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "appflow_offset: AppearanceFlowModel 128x128x3, batch %d per GPU, Adam lr 1e-4, "
+                               "random-init weights (reference initialisers)" % args.batch,
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                   "launches_per_step": g.n_launch_fwd + g.n_launch_bwd + 1},
+        "loss": round(loss, 6),
+    }
+    if timing and kern:
+        gpu_ms = sum(k['ms'] for k in kern.values())
+        mfma = {n: k for n, k in kern.items() if k['flops'] > 0}
+        conv_ms = sum(k['ms'] for k in mfma.values())
+        conv_fl = sum(k['flops'] for k in mfma.values())
+        dom_name, dom = max(kern.items(), key=lambda kv: kv[1]['ms'])
+        if dom['flops'] > 0:
+            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
+        else:
+            ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4)}
+        roof.update({"launches_per_step": dom['launches'], "avg_launch_ms": round(dom['ms'] / dom['launches'], 5),
+                     "share_of_gpu_time": round(dom['ms'] / gpu_ms, 4), "traffic": None})
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                roof["traffic"] = json.load(open(tfile)).get(dom_name)
+            except Exception:
+                pass
+        out["roofline"] = roof
+        out["stack"] = {"gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
+                        "mfma_kernels_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                        "mfma_kernels_frac_of_f32_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                        "mfma_kernels_share_of_gpu_time": round(conv_ms / gpu_ms, 4)}
+        if args.dump_kernels and rank == 0:
+            for n, k in sorted(kern.items(), key=lambda kv: -kv[1]['ms']):
+                rate = ("%7.1f TF/s" % (k['flops'] / k['ms'] / 1e9)) if k['flops'] > 0 else ("%7.0f GB/s" % (k['bytes'] / k['ms'] / 1e6))
+                print("%-34s launches=%3d  ms/step=%8.4f  %s" % (n, k['launches'], k['ms'], rate), file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

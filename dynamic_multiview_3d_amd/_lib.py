@@ -56,6 +56,11 @@ STATUS_FUNCS = {
     "mv3d_plan_begin": [_vp],
     "mv3d_plan_end": [],
     "mv3d_plan_run": [_vp, _vp],
+    "mv3d_plan_profile": [_vp, _i],
+    "mv3d_plan_profile_collect": [_vp],
+    "mv3d_plan_profile_reset": [_vp],
+    "mv3d_plan_op_info": [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                          C.POINTER(C.c_double), C.POINTER(C.c_int)],
 }
 OTHER_FUNCS = {
     "mv3d_version": (C.c_char_p, []),
@@ -109,6 +114,17 @@ def lib():
     if _lib is None:
         _lib = _Lib(LIB_PATH)
     return _lib
+
+
+def plan_ops(plan):
+    """[(kernel label, algorithmic flops, algorithmic bytes, total ms, timed runs)] of a plan."""
+    l = lib()
+    out = []
+    for i in range(l.plan_size(plan)):
+        name, fl, by, ms, runs = C.c_char_p(), C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        l.plan_op_info(plan, i, C.byref(name), C.byref(fl), C.byref(by), C.byref(ms), C.byref(runs))
+        out.append((name.value.decode(), fl.value, by.value, ms.value, runs.value))
+    return out
 
 
 def epilogue(bias=None, act=ACT_NONE, leak=0.2, gmask_act=ACT_NONE, gmask_leak=0.2, gmask_ref=None, gmask_ld=0):

@@ -8,13 +8,22 @@
 namespace mv3d {
 
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// What one recorded launch is, for the bench's roofline accounting: kernel label, algorithmic
+// FLOPs and algorithmic HBM bytes of this launch (DESIGN.md states the formulas).
+struct OpInfo {
+    const char* name;
+    double flops;
+    double bytes;
+};
+
 bool recording();
-void record(std::function<int(hipStream_t)> fn);
+void record(std::function<int(hipStream_t)> fn, const OpInfo& info);
 
 // Launch now, or append to the plan being recorded on this thread (mv3d_plan_begin).
+// Every dispatch() is exactly ONE kernel launch.
 template <class F>
-inline int dispatch(void* stream, F fn) {
-    if (recording()) { record(std::function<int(hipStream_t)>(fn)); return MV3D_OK; }
+inline int dispatch(void* stream, const OpInfo& info, F fn) {
+    if (recording()) { record(std::function<int(hipStream_t)>(fn), info); return MV3D_OK; }
     return fn(reinterpret_cast<hipStream_t>(stream));
 }
 

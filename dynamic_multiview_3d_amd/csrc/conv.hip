@@ -453,7 +453,15 @@ static size_t igemm_plan(IgemmParams& p, int* cfg_out, dim3* grid_out) {
     return ksplit > 1 ? (size_t)ksplit * p.N * p.Hc * p.Wc * p.Cc * sizeof(float) : 0;
 }
 
-static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, const char* who) {
+static const char* igemm_name(int cfg, bool vec, bool bkmajor) {
+    static const char* names[3][2][2] = {
+        {{"igemm<128x32,scalarA,nmajorB>", "igemm<128x32,scalarA,kmajorB>"}, {"igemm<128x32,vecA,nmajorB>", "igemm<128x32,vecA,kmajorB>"}},
+        {{"igemm<128x64,scalarA,nmajorB>", "igemm<128x64,scalarA,kmajorB>"}, {"igemm<128x64,vecA,nmajorB>", "igemm<128x64,vecA,kmajorB>"}},
+        {{"igemm<64x64,scalarA,nmajorB>", "igemm<64x64,scalarA,kmajorB>"}, {"igemm<64x64,vecA,nmajorB>", "igemm<64x64,vecA,kmajorB>"}}};
+    return names[cfg][vec ? 1 : 0][bkmajor ? 1 : 0];
+}
+
+static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes) {
     const bool bkmajor = (p.w_ns == 1);
     const bool vec = !p.fold && (p.Ca % 4 == 0) && (p.a_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
     if (!bkmajor && p.Cc <= 4 && p.so_h * p.so_w <= 4 && (p.Ka % 4 == 0) && (p.a_ld % 4 == 0) &&
@@ -466,7 +474,8 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
         if (lds <= 64 * 1024) {
             dim3 grid(cdiv(maxMp, 256), 1, p.so_h * p.so_w);
             p.ksplit = 1;
-            return dispatch(stream, [=](hipStream_t s) {
+            static const char* tn[4] = {"thin_feat2img<1>", "thin_feat2img<2>", "thin_feat2img<3>", "thin_feat2img<4>"};
+            return dispatch(stream, OpInfo{tn[p.Cc - 1], flops, bytes}, [=](hipStream_t s) {
                 switch (p.Cc) {
                     case 1: thin_feat2img_kernel<1><<<grid, 256, lds, s>>>(p); break;
                     case 2: thin_feat2img_kernel<2><<<grid, 256, lds, s>>>(p); break;
@@ -486,20 +495,26 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
         need = 0;
     }
     p.Part = (float*)ws;
-    return dispatch(stream, [=](hipStream_t s) {
+    int rc = dispatch(stream, OpInfo{igemm_name(cfg, vec, bkmajor), flops, bytes}, [=](hipStream_t s) {
         if (cfg == 0) launch_igemm_cfg<4, 1, 1>(p, vec, bkmajor, grid, s);
         else if (cfg == 1) launch_igemm_cfg<4, 1, 2>(p, vec, bkmajor, grid, s);
         else launch_igemm_cfg<2, 1, 1>(p, vec, bkmajor, grid, s);
-        int rc = launched(who);
-        if (rc != MV3D_OK) return rc;
-        if (p.ksplit > 1) {
-            int64_t total = (int64_t)p.N * p.Hc * p.Wc * p.Cc;
-            int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
-            igemm_splitk_epilogue<<<blocks, 256, 0, s>>>(p);
-            rc = launched("igemm_splitk_epilogue");
-        }
-        return rc;
+        return launched(who);
     });
+    if (rc != MV3D_OK || p.ksplit == 1) return rc;
+    const int64_t total = (int64_t)p.N * p.Hc * p.Wc * p.Cc;
+    const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
+    return dispatch(stream, OpInfo{"igemm_splitk_epilogue", 0.0, (double)total * 4.0 * (p.ksplit + 1)}, [=](hipStream_t s) {
+        igemm_splitk_epilogue<<<blocks, 256, 0, s>>>(p);
+        return launched("igemm_splitk_epilogue");
+    });
+}
+
+static inline double conv_flops(const mv3d_conv_geom* g) {
+    return 2.0 * g->N * g->Ho * g->Wo * g->kh * g->kw * (double)g->C * g->K;
+}
+static inline double conv_bytes(const mv3d_conv_geom* g) {
+    return 4.0 * ((double)g->N * g->H * g->W * g->C + (double)g->N * g->Ho * g->Wo * g->K + (double)g->kh * g->kw * g->C * g->K);
 }
 
 // image side -> feature side (conv fwd / deconv dgrad)
@@ -531,7 +546,7 @@ static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, voi
     p.tap_begin[0] = 0; p.tap_begin[1] = nt;
     p.w_tap_stride = g->C * g->K; p.w_ks = g->K; p.w_ns = 1;
     fill_epilogue(p, epi);
-    return run_igemm(p, ws, ws_bytes, stream, who);
+    return run_igemm(p, ws, ws_bytes, stream, who, conv_flops(g), conv_bytes(g));
 }
 
 // feature side -> image side (conv dgrad / deconv fwd), one dense sub-convolution per stride phase
@@ -571,7 +586,7 @@ static int feat2img(const mv3d_conv_geom* g, const void* feat, const void* w, vo
     p.fold = 0; p.Ka = g->K;
     p.w_tap_stride = g->C * g->K; p.w_ks = 1; p.w_ns = g->K;
     fill_epilogue(p, epi);
-    return run_igemm(p, ws, ws_bytes, stream, who);
+    return run_igemm(p, ws, ws_bytes, stream, who, conv_flops(g), conv_bytes(g));
 }
 
 static void filtgrad_plan(const mv3d_conv_geom* g, FiltgradParams& p, int* nt_out, int* nslab_out) {
@@ -632,13 +647,19 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
     dim3 grid(cdiv(p.ctiles * p.ktiles * p.ntap, 4), nslab);
     float* dfp = (float*)df; float* dbp = (float*)db;
     const int K = g->K;
-    return dispatch(stream, [=](hipStream_t s) {
+    rc = dispatch(stream, OpInfo{NT == 2 ? "filtgrad<NT=2>" : "filtgrad<NT=1>", conv_flops(g), conv_bytes(g)}, [=](hipStream_t s) {
         if (NT == 2) filtgrad_kernel<2><<<grid, 256, 0, s>>>(p);
         else filtgrad_kernel<1><<<grid, 256, 0, s>>>(p);
-        int r = launched(who);
-        if (r != MV3D_OK || nslab == 1) return r;
+        return launched(who);
+    });
+    if (rc != MV3D_OK || nslab == 1) return rc;
+    rc = dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)fcount * (nslab + 1)}, [=](hipStream_t s) {
         reduce_slabs_kernel<<<(int)std::min<int64_t>(cdiv64(fcount, 256), 2048), 256, 0, s>>>(p.out, nslab, fcount, dfp);
-        if (dbp) reduce_slabs_kernel<<<cdiv(K, 256), 256, 0, s>>>(p.bias_out, nslab, K, dbp);
+        return launched("reduce_slabs_kernel");
+    });
+    if (rc != MV3D_OK || !dbp) return rc;
+    return dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)K * (nslab + 1)}, [=](hipStream_t s) {
+        reduce_slabs_kernel<<<cdiv(K, 256), 256, 0, s>>>(p.bias_out, nslab, K, dbp);
         return launched("reduce_slabs_kernel");
     });
 }

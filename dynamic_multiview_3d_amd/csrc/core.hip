@@ -4,8 +4,18 @@
 #include <stdio.h>
 #include <vector>
 
+struct PlanOp {
+    std::function<int(hipStream_t)> fn;
+    mv3d::OpInfo info;
+    double total_ms;
+    int runs;
+};
+
 struct mv3d_plan {
-    std::vector<std::function<int(hipStream_t)>> ops;
+    std::vector<PlanOp> ops;
+    bool profile = false;
+    std::vector<hipEvent_t> pool;   // 2 events per op per profiled run, collected in bulk
+    size_t used = 0;
 };
 
 namespace mv3d {
@@ -20,23 +30,26 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 bool recording() { return g_rec != nullptr; }
-void record(std::function<int(hipStream_t)> fn) { g_rec->ops.push_back(std::move(fn)); }
+void record(std::function<int(hipStream_t)> fn, const OpInfo& info) { g_rec->ops.push_back(PlanOp{std::move(fn), info, 0.0, 0}); }
 }  // namespace mv3d
 
 extern "C" {
 
-const char* mv3d_version(void) { return "mv3d_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* mv3d_version(void) { return "mv3d_hip 0.2 (gfx950, fp32 MFMA)"; }
 const char* mv3d_last_error(void) { return mv3d::g_err; }
 
 mv3d_plan* mv3d_plan_create(void) { return new mv3d_plan(); }
 void mv3d_plan_destroy(mv3d_plan* p) {
+    if (!p) return;
     if (mv3d::g_rec == p) mv3d::g_rec = nullptr;
+    for (hipEvent_t e : p->pool) (void)hipEventDestroy(e);
     delete p;
 }
 int mv3d_plan_begin(mv3d_plan* p) {
     if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_begin: null plan");
     if (mv3d::g_rec) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_begin: a plan is already recording on this thread");
     p->ops.clear();
+    p->used = 0;
     mv3d::g_rec = p;
     return MV3D_OK;
 }
@@ -46,14 +59,75 @@ int mv3d_plan_end(void) {
     return MV3D_OK;
 }
 int mv3d_plan_size(const mv3d_plan* p) { return p ? (int)p->ops.size() : 0; }
-int mv3d_plan_run(const mv3d_plan* p, void* stream) {
+
+int mv3d_plan_run(mv3d_plan* p, void* stream) {
     if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run: null plan");
     if (mv3d::g_rec) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run: cannot run while recording");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!p->profile) {
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            int rc = p->ops[i].fn(s);
+            if (rc != MV3D_OK) return rc;
+        }
+        return MV3D_OK;
+    }
+    // profiled run: bracket every launch with HIP events on the launch stream; no host sync here
+    const size_t need = p->used + 2 * p->ops.size();
+    while (p->pool.size() < need) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_plan_run: hipEventCreate failed");
+        p->pool.push_back(e);
+    }
     for (size_t i = 0; i < p->ops.size(); ++i) {
-        int rc = p->ops[i](s);
+        (void)hipEventRecord(p->pool[p->used + 2 * i], s);
+        int rc = p->ops[i].fn(s);
+        (void)hipEventRecord(p->pool[p->used + 2 * i + 1], s);
         if (rc != MV3D_OK) return rc;
     }
+    p->used = need;
+    return MV3D_OK;
+}
+
+int mv3d_plan_profile(mv3d_plan* p, int enable) {
+    if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_profile: null plan");
+    p->profile = enable != 0;
+    return MV3D_OK;
+}
+
+// Host-synchronising: folds all profiled runs since the last collect into per-op totals.
+int mv3d_plan_profile_collect(mv3d_plan* p) {
+    if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_profile_collect: null plan");
+    const size_t n = p->ops.size();
+    if (n == 0 || p->used == 0) return MV3D_OK;
+    if (hipEventSynchronize(p->pool[p->used - 1]) != hipSuccess)
+        return mv3d::fail(MV3D_E_HIP, "mv3d_plan_profile_collect: hipEventSynchronize failed");
+    for (size_t base = 0; base + 2 * n <= p->used; base += 2 * n)
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p->pool[base + 2 * i], p->pool[base + 2 * i + 1]) == hipSuccess) {
+                p->ops[i].total_ms += ms;
+                p->ops[i].runs += 1;
+            }
+        }
+    p->used = 0;
+    return MV3D_OK;
+}
+
+int mv3d_plan_profile_reset(mv3d_plan* p) {
+    if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_profile_reset: null plan");
+    for (auto& o : p->ops) { o.total_ms = 0.0; o.runs = 0; }
+    p->used = 0;
+    return MV3D_OK;
+}
+
+int mv3d_plan_op_info(const mv3d_plan* p, int i, const char** name, double* flops, double* bytes, double* total_ms, int* runs) {
+    if (!p || i < 0 || i >= (int)p->ops.size()) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_op_info: bad index");
+    const PlanOp& o = p->ops[i];
+    if (name) *name = o.info.name;
+    if (flops) *flops = o.info.flops;
+    if (bytes) *bytes = o.info.bytes;
+    if (total_ms) *total_ms = o.total_ms;
+    if (runs) *runs = o.runs;
     return MV3D_OK;
 }
 

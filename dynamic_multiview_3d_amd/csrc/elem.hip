@@ -173,7 +173,7 @@ int mv3d_warp_resample_fwd(int N, int H, int W, int Hs, int Ws, int C, const voi
     if (N > 65535) return fail(MV3D_E_UNSUPPORTED, "mv3d_warp_resample_fwd: batch > 65535");
     ResampleParams p = {(const float*)src, (const float*)flow, nullptr, (float*)warp_out, (float*)gen, nullptr, N, H, W, Hs, Ws, C, flow_ld, 0};
     dim3 grid(cdiv(W, 32), cdiv(H, 8), N);
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"resample_fwd", 0.0, (double)N * H * W * (8.0 + 8.0 * C)}, [=](hipStream_t s) {
         resample_kernel<false><<<grid, 256, 0, s>>>(p);
         return launched("resample_kernel<fwd>");
     });
@@ -186,7 +186,7 @@ int mv3d_warp_resample_bwd(int N, int H, int W, int Hs, int Ws, int C, const voi
     if (N > 65535) return fail(MV3D_E_UNSUPPORTED, "mv3d_warp_resample_bwd: batch > 65535");
     ResampleParams p = {(const float*)src, (const float*)flow, (const float*)dgen, nullptr, nullptr, (float*)dflow, N, H, W, Hs, Ws, C, flow_ld, dflow_ld};
     dim3 grid(cdiv(W, 32), cdiv(H, 8), N);
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"resample_bwd", 0.0, (double)N * H * W * (16.0 + 8.0 * C)}, [=](hipStream_t s) {
         resample_kernel<true><<<grid, 256, 0, s>>>(p);
         return launched("resample_kernel<bwd>");
     });
@@ -197,7 +197,7 @@ int mv3d_pixel_loss(int64_t pixels, int ch, const void* a, const void* b, const 
     if (pixels <= 0 || ch <= 0 || (kind != 1 && kind != 2)) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: bad arguments");
     if (!a || !b || !loss_accum) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: null pointer");
     const int blocks = (int)std::min<int64_t>(cdiv64(pixels * ch, 256 * 8), 1024);
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"pixel_loss", 0.0, (double)pixels * ch * (grad ? 12.0 : 8.0)}, [=](hipStream_t s) {
         pixel_loss_kernel<<<blocks, 256, 0, s>>>(pixels, ch, (const float*)a, (const float*)b, (const float*)mask, kind, weight,
                                                 (float*)loss_accum, (float*)grad);
         return launched("pixel_loss_kernel");
@@ -207,7 +207,7 @@ int mv3d_pixel_loss(int64_t pixels, int ch, const void* a, const void* b, const 
 int mv3d_fill(void* dst, int64_t count, float value, void* stream) {
     if (!dst || count < 0) return fail(MV3D_E_INVAL, "mv3d_fill: bad arguments");
     if (count == 0) return MV3D_OK;
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"fill", 0.0, 4.0 * count}, [=](hipStream_t s) {
         fill_kernel<<<grid_for(count), 256, 0, s>>>((float*)dst, count, value);
         return launched("fill_kernel");
     });
@@ -221,7 +221,7 @@ int mv3d_adam_step(int64_t count, void* p, const void* g, void* m, void* v, floa
     const float alpha = lr * sqrtf(1.0f - beta2_power) / (1.0f - beta1_power);
     const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
     const int blocks = (int)std::min<int64_t>(cdiv64(count / 4 + 1, 256), 4096);
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"adam", 0.0, 28.0 * count}, [=](hipStream_t s) {
         adam_kernel<<<blocks, 256, 0, s>>>(count, (float*)p, (const float*)g, (float*)m, (float*)v, alpha, omb1, omb2, eps, grad_scale);
         return launched("adam_kernel");
     });
@@ -229,7 +229,7 @@ int mv3d_adam_step(int64_t count, void* p, const void* g, void* m, void* v, floa
 
 int mv3d_act_fwd(int64_t rows, int ch, const void* x, int x_ld, void* y, int y_ld, int act, float leak, void* stream) {
     if (rows <= 0 || ch <= 0 || !x || !y || x_ld < ch || y_ld < ch) return fail(MV3D_E_INVAL, "mv3d_act_fwd: bad arguments");
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"act_fwd", 0.0, 8.0 * rows * ch}, [=](hipStream_t s) {
         act_fwd_kernel<<<grid_for(rows * ch), 256, 0, s>>>(rows, ch, (const float*)x, x_ld, (float*)y, y_ld, act, leak);
         return launched("act_fwd_kernel");
     });
@@ -238,7 +238,7 @@ int mv3d_act_fwd(int64_t rows, int ch, const void* x, int x_ld, void* y, int y_l
 int mv3d_act_bwd(int64_t rows, int ch, const void* dy, int dy_ld, const void* ref, int ref_ld, void* dx, int dx_ld,
                  int act, float leak, void* stream) {
     if (rows <= 0 || ch <= 0 || !dy || !ref || !dx || dy_ld < ch || ref_ld < ch || dx_ld < ch) return fail(MV3D_E_INVAL, "mv3d_act_bwd: bad arguments");
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"act_bwd", 0.0, 12.0 * rows * ch}, [=](hipStream_t s) {
         act_bwd_kernel<<<grid_for(rows * ch), 256, 0, s>>>(rows, ch, (const float*)dy, dy_ld, (const float*)ref, ref_ld, (float*)dx, dx_ld, act, leak);
         return launched("act_bwd_kernel");
     });
@@ -247,7 +247,7 @@ int mv3d_act_bwd(int64_t rows, int ch, const void* dy, int dy_ld, const void* re
 int mv3d_copy2d(int64_t rows, int ch, const void* src, int64_t src_ld, int64_t src_row_div, void* dst, int64_t dst_ld,
                 int accumulate, void* stream) {
     if (rows <= 0 || ch <= 0 || !src || !dst || src_row_div < 1) return fail(MV3D_E_INVAL, "mv3d_copy2d: bad arguments");
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"copy2d", 0.0, 8.0 * rows * ch}, [=](hipStream_t s) {
         copy2d_kernel<<<grid_for(rows * ch), 256, 0, s>>>(rows, ch, (const float*)src, src_ld, src_row_div, (float*)dst, dst_ld, accumulate);
         return launched("copy2d_kernel");
     });
@@ -255,7 +255,7 @@ int mv3d_copy2d(int64_t rows, int ch, const void* src, int64_t src_ld, int64_t s
 
 int mv3d_group_sum(int64_t groups, int group, int ch, const void* src, int64_t src_ld, void* dst, int64_t dst_ld, void* stream) {
     if (groups <= 0 || group <= 0 || ch <= 0 || !src || !dst) return fail(MV3D_E_INVAL, "mv3d_group_sum: bad arguments");
-    return dispatch(stream, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"group_sum", 0.0, 4.0 * groups * ch * (group + 1)}, [=](hipStream_t s) {
         group_sum_kernel<<<grid_for(groups * ch), 256, 0, s>>>(groups, group, ch, (const float*)src, src_ld, (float*)dst, dst_ld);
         return launched("group_sum_kernel");
     });

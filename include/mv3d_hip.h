@@ -150,7 +150,17 @@ void mv3d_plan_destroy(mv3d_plan* p);
 int mv3d_plan_begin(mv3d_plan* p);
 int mv3d_plan_end(void);
 int mv3d_plan_size(const mv3d_plan* p);
-int mv3d_plan_run(const mv3d_plan* p, void* stream);
+int mv3d_plan_run(mv3d_plan* p, void* stream);
+/* Per-launch timing for the roofline report: with profiling enabled, mv3d_plan_run brackets every
+ * recorded launch with hipEventRecord on the launch stream (no host synchronisation);
+ * mv3d_plan_profile_collect() synchronises once and folds all runs into per-op totals.
+ * mv3d_plan_op_info returns the kernel label, the algorithmic FLOPs and HBM bytes of launch i
+ * (formulas in DESIGN.md), the accumulated milliseconds and the number of timed runs. */
+int mv3d_plan_profile(mv3d_plan* p, int enable);
+int mv3d_plan_profile_collect(mv3d_plan* p);
+int mv3d_plan_profile_reset(mv3d_plan* p);
+int mv3d_plan_op_info(const mv3d_plan* p, int i, const char** name, double* flops, double* bytes,
+                      double* total_ms, int* runs);
 
 #ifdef __cplusplus
 }

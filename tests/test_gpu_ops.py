@@ -252,7 +252,8 @@ def test_masked_pixel_loss():
     m = (RNG.uniform(size=(2, 8, 8, 1)) > 0.5).astype(np.float32)
     loss = torch.zeros(4, device='cuda')
     grad = torch.empty(a.shape, device='cuda')
-    L().pixel_loss(128, 3, dev(a).data_ptr(), dev(b).data_ptr(), dev(m).data_ptr(), 2, 1.0, loss.data_ptr(), grad.data_ptr(), stream())
+    da, db_, dm = dev(a), dev(b), dev(m)          # keep the device buffers alive across the launch
+    L().pixel_loss(128, 3, da.data_ptr(), db_.data_ptr(), dm.data_ptr(), 2, 1.0, loss.data_ptr(), grad.data_ptr(), stream())
     d = (a - b) * m
     np.testing.assert_allclose(host(loss)[0], (d * d).sum(3).mean(), rtol=2e-6)
     np.testing.assert_allclose(host(grad), 2 * d * m / 128, rtol=1e-6, atol=1e-9)
@@ -268,7 +269,8 @@ def test_adam_bit_exact_vs_oracle():
     for t in range(4):
         g = (RNG.standard_normal(n) * 10.0 ** RNG.integers(-6, 1)).astype(np.float32)
         ops.adam_step(p, g, m, v, b1p, b2p, 1e-4)
-        L().adam_step(n, dp.data_ptr(), dev(g).data_ptr(), dm.data_ptr(), dv.data_ptr(), 1e-4, 0.9, 0.999, 1e-8,
+        dg = dev(g)
+        L().adam_step(n, dp.data_ptr(), dg.data_ptr(), dm.data_ptr(), dv.data_ptr(), 1e-4, 0.9, 0.999, 1e-8,
                       float(b1p), float(b2p), 1.0, stream())
         b1p = np.float32(b1p * np.float32(0.9))
         b2p = np.float32(b2p * np.float32(0.999))
