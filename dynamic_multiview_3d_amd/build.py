@@ -12,6 +12,8 @@ LIB = os.path.join(HERE, "libmv3d_hip.so")
 UNITS = {
     "core.hip": [],
     "conv.hip": [],
+    "hconv.hip": [],
+    "wgrad_tile.hip": [],
     "elem.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -35,7 +37,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "mv3d_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "mv3d_hip.h")]
     objs = []
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)

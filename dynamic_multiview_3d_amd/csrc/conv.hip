@@ -14,40 +14,10 @@
 // conv therefore becomes s*s dense sub-convolutions with no multiplications by structural zeros.
 // Tiles are staged global -> registers -> LDS (next tile's loads in flight during the MFMAs) and
 // multiplied with v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
-#include "common.h"
+#include "conv_common.h"
 #include <algorithm>
 
 namespace mv3d {
-
-struct IgemmTap { int8_t dh, dw; int16_t widx; };
-
-struct IgemmParams {
-    const float* A;      // input activations
-    const float* Wt;     // filter [kh*kw][C][K]
-    float* Out;          // output activations
-    float* Part;         // split-K partials [ksplit][N*Hc*Wc][Cc] (ksplit > 1)
-    int N, Ha, Wa, Ca, a_ld;
-    int Hc, Wc, Cc, c_ld;
-    int sa_h, sa_w;      // input coordinate multiplier
-    int so_h, so_w;      // output phase stride
-    int Hp[2], Wp[2];    // per-phase output sub-grid
-    int tap_begin[5];
-    IgemmTap taps[36];
-    int fold;            // 1: a tap covers kw*Ca contiguous elements of a dense NHWC row (small Ca)
-    int Ka;              // reduction extent per tap
-    int w_tap_stride, w_ks, w_ns;
-    int ksplit;
-    // epilogue
-    const float* bias; int act; float leak;
-    int gact; float gleak; const float* gref; int g_ld;
-};
-
-__device__ __forceinline__ float epilogue_value(const IgemmParams& p, float v, int64_t pix, int col) {
-    if (p.bias) v += p.bias[col];
-    v = act_apply(v, p.act, p.leak);
-    if (p.gact != MV3D_ACT_NONE) v *= act_grad_from_out(p.gref[pix * p.g_ld + col], p.gact, p.gleak);
-    return v;
-}
 
 // WM waves along M (4/WM along N); each wave owns a (32*MT) x (32*NT) output tile.
 template <int WM, int MT, int NT, bool VEC, bool BKMAJOR>
@@ -370,12 +340,32 @@ __global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
     }
 }
 
+// Sums the per-slab partial filters in a fixed order (deterministic).  256 threads = 16 consecutive
+// elements x 16 slab lanes: each thread adds every 16th slab (independent loads in flight), the 16
+// lanes of an element are combined through LDS.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, int nslab, int64_t count,
                                                           float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += part[(int64_t)k * count + i];
-        out[i] = s;
+    __shared__ float s_sum[16][17];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < count) {
+        int k = sl;
+        for (; k + 48 < nslab; k += 64) {
+            s0 += part[(int64_t)k * count + i];
+            s1 += part[(int64_t)(k + 16) * count + i];
+            s2 += part[(int64_t)(k + 32) * count + i];
+            s3 += part[(int64_t)(k + 48) * count + i];
+        }
+        for (; k < nslab; k += 16) s0 += part[(int64_t)k * count + i];
+    }
+    s_sum[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += s_sum[j][e];
+        out[i] = t;
     }
 }
 
@@ -486,6 +476,10 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
             });
         }
     }
+    {
+        int hrc = try_hconv(p, stream, who, flops, bytes);
+        if (hrc != 1) return hrc;
+    }
     int cfg; dim3 grid;
     size_t need = igemm_plan(p, &cfg, &grid);
     if (need > ws_bytes || (need && !ws)) {
@@ -589,6 +583,10 @@ static int feat2img(const mv3d_conv_geom* g, const void* feat, const void* w, vo
     return run_igemm(p, ws, ws_bytes, stream, who, conv_flops(g), conv_bytes(g));
 }
 
+struct WgTileParams;
+bool wgrad_tile_plan(const mv3d_conv_geom* g, struct WgTileParams* out, int* nslab_out, int* cfg_out, size_t* lds_out);
+int wgrad_tile_launch_erased(const mv3d_conv_geom* g, const void* img, const void* feat, void* out, void* bias_out, void* stream, const char* who, int* nslab_out);
+
 static void filtgrad_plan(const mv3d_conv_geom* g, FiltgradParams& p, int* nt_out, int* nslab_out) {
     int ho, wo;
     same_pad(g->H, g->kh, g->sh, &ho, &p.pt);
@@ -617,10 +615,14 @@ static void filtgrad_plan(const mv3d_conv_geom* g, FiltgradParams& p, int* nt_ou
     *nslab_out = nslab;
 }
 
+int wgrad_tile_nslab(const mv3d_conv_geom* g);
+
 static size_t filtgrad_ws_bytes(const mv3d_conv_geom* g) {
     FiltgradParams p = {};
     int NT, nslab;
     filtgrad_plan(g, p, &NT, &nslab);
+    const int tiled = wgrad_tile_nslab(g);
+    if (tiled > 0) nslab = tiled;
     if (nslab == 1) return 0;
     return (size_t)nslab * ((size_t)g->kh * g->kw * g->C * g->K + g->K) * sizeof(float);
 }
@@ -630,10 +632,36 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
     int rc = check_geom(g, who);
     if (rc != MV3D_OK) return rc;
     if (!img || !feat || !df) return fail(MV3D_E_INVAL, "%s: null tensor pointer", who);
+    const int64_t fcount = (int64_t)g->kh * g->kw * g->C * g->K;
+    float* dfp = (float*)df; float* dbp = (float*)db;
+    const int K = g->K;
+    {   // tiled persistent kernel for the layers that carry the FLOPs
+        const int tiled = wgrad_tile_nslab(g);
+        if (tiled > 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0) {
+            float* part = dfp; float* bpart = dbp;
+            if (tiled > 1) {
+                size_t need = (size_t)tiled * (fcount + K) * sizeof(float);
+                if (!ws || ws_bytes < need) return fail(MV3D_E_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
+                part = (float*)ws;
+                bpart = db ? (float*)ws + (int64_t)tiled * fcount : nullptr;
+            }
+            int ns = 0;
+            rc = wgrad_tile_launch_erased(g, img, feat, part, bpart, stream, who, &ns);
+            if (rc != MV3D_OK || ns == 1) return rc;
+            rc = dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)fcount * (ns + 1)}, [=](hipStream_t s) {
+                reduce_slabs_kernel<<<(int)cdiv64(fcount, 16), 256, 0, s>>>(part, ns, fcount, dfp);
+                return launched("reduce_slabs_kernel");
+            });
+            if (rc != MV3D_OK || !dbp) return rc;
+            return dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)K * (ns + 1)}, [=](hipStream_t s) {
+                reduce_slabs_kernel<<<cdiv(K, 16), 256, 0, s>>>(bpart, ns, K, dbp);
+                return launched("reduce_slabs_kernel");
+            });
+        }
+    }
     FiltgradParams p = {};
     int NT, nslab;
     filtgrad_plan(g, p, &NT, &nslab);
-    const int64_t fcount = (int64_t)g->kh * g->kw * g->C * g->K;
     p.img = (const float*)img; p.feat = (const float*)feat;
     if (nslab > 1) {
         size_t need = (size_t)nslab * (fcount + g->K) * sizeof(float);
@@ -645,8 +673,6 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
         p.bias_out = (float*)db;
     }
     dim3 grid(cdiv(p.ctiles * p.ktiles * p.ntap, 4), nslab);
-    float* dfp = (float*)df; float* dbp = (float*)db;
-    const int K = g->K;
     rc = dispatch(stream, OpInfo{NT == 2 ? "filtgrad<NT=2>" : "filtgrad<NT=1>", conv_flops(g), conv_bytes(g)}, [=](hipStream_t s) {
         if (NT == 2) filtgrad_kernel<2><<<grid, 256, 0, s>>>(p);
         else filtgrad_kernel<1><<<grid, 256, 0, s>>>(p);
@@ -654,12 +680,12 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
     });
     if (rc != MV3D_OK || nslab == 1) return rc;
     rc = dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)fcount * (nslab + 1)}, [=](hipStream_t s) {
-        reduce_slabs_kernel<<<(int)std::min<int64_t>(cdiv64(fcount, 256), 2048), 256, 0, s>>>(p.out, nslab, fcount, dfp);
+        reduce_slabs_kernel<<<(int)cdiv64(fcount, 16), 256, 0, s>>>(p.out, nslab, fcount, dfp);
         return launched("reduce_slabs_kernel");
     });
     if (rc != MV3D_OK || !dbp) return rc;
     return dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)K * (nslab + 1)}, [=](hipStream_t s) {
-        reduce_slabs_kernel<<<cdiv(K, 256), 256, 0, s>>>(p.bias_out, nslab, K, dbp);
+        reduce_slabs_kernel<<<cdiv(K, 16), 256, 0, s>>>(p.bias_out, nslab, K, dbp);
         return launched("reduce_slabs_kernel");
     });
 }

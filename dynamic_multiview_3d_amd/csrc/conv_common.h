@@ -1,0 +1,42 @@
+// Shared between conv.hip (generic implicit GEMM) and hconv.hip (halo-tile kernels).
+#pragma once
+#include "common.h"
+
+namespace mv3d {
+
+struct IgemmTap { int8_t dh, dw; int16_t widx; };
+
+struct IgemmParams {
+    const float* A;      // input activations
+    const float* Wt;     // filter [kh*kw][C][K]
+    float* Out;          // output activations
+    float* Part;         // split-K partials [ksplit][N*Hc*Wc][Cc] (ksplit > 1)
+    int N, Ha, Wa, Ca, a_ld;
+    int Hc, Wc, Cc, c_ld;
+    int sa_h, sa_w;      // input coordinate multiplier
+    int so_h, so_w;      // output phase stride
+    int Hp[2], Wp[2];    // per-phase output sub-grid
+    int tap_begin[5];
+    IgemmTap taps[36];
+    int fold;            // 1: a tap covers kw*Ca contiguous elements of a dense NHWC row (small Ca)
+    int Ka;              // reduction extent per tap
+    int w_tap_stride, w_ks, w_ns;
+    int ksplit;
+    // epilogue
+    const float* bias; int act; float leak;
+    int gact; float gleak; const float* gref; int g_ld;
+};
+
+__device__ __forceinline__ float epilogue_value(const IgemmParams& p, float v, int64_t pix, int col) {
+    if (p.bias) v += p.bias[col];
+    v = act_apply(v, p.act, p.leak);
+    if (p.gact != MV3D_ACT_NONE) v *= act_grad_from_out(p.gref[pix * p.g_ld + col], p.gact, p.gleak);
+    return v;
+}
+
+
+// hconv.hip: returns MV3D_OK after dispatching, or 1 if the problem is not eligible for the
+// halo-tile kernel (caller falls back to the generic igemm).
+int try_hconv(const IgemmParams& p, void* stream, const char* who, double flops, double bytes);
+
+}  // namespace mv3d

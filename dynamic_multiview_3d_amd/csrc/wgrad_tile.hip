@@ -1,0 +1,303 @@
+// Filter gradient (conv / deconv wgrad) for the layers that carry the FLOPs -- tiled, persistent.
+//
+//   df[tap][c][k] = sum_pixels img[pixel + tap][c] * feat[pixel][k]
+//
+// A workgroup owns one (32-channel c-tile) x (32*NKT k-tile) block of the filter for ALL taps and
+// walks a slab of spatial tiles (128 output pixels each).  Per tile the image halo
+// ((TH-1)*s + kh) x ((TW-1)*s + kw) x 32c and the feature tile 128 x 32*NKT are staged in LDS once
+// and reused by every tap; the 4 waves split the (tap, k-tile) items and keep their partial filters
+// in accumulator registers across the whole slab (up to 13 x 32x32 fp32 tiles = 208 registers per
+// lane).  The next tile's global loads are issued before the current tile's MFMAs and written to
+// LDS afterwards, so HBM/L2 latency hides under ~30k MFMA cycles per tile.
+// MFMA operands: A[i = channel][k-slot = pixel parity], B[k-slot][j = feature channel]; both are
+// consecutive-lane ds_read_b32 of 128-byte LDS rows (conflict-free, no padding).
+// One partial filter per workgroup is written at the end; reduce_slabs_kernel sums them in a fixed
+// order (no float atomics).
+#include "conv_common.h"
+#include <algorithm>
+
+namespace mv3d {
+
+struct WgTileParams {
+    const float* img; const float* feat;
+    float* out; float* bias_out;
+    int N, H, W, C, img_ld;
+    int Ho, Wo, K, feat_ld;
+    int sh, sw, pt, pl, kw;
+    int TH, TW, tw_shift, tiles_h, tiles_w, HR, HC;
+    int ntaps, nitems, ipw;
+    int IW, PH;          // 8 waves = IW item groups x PH pixel-pair ranges
+    int ctiles;
+    int ntiles_total, tiles_per_slab;
+};
+
+__device__ float4 g_zero16[4];        // 64 bytes of zeros in the code object: source of out-of-image LDS-DMA lanes
+
+// 16 bytes per lane global -> LDS without a VGPR round trip.  The LDS destination of a wave
+// instruction is (wave-uniform base) + lane*16, i.e. 1 KiB contiguous = 8 rows of 128 bytes.
+__device__ __forceinline__ void dma16(const float* gsrc, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int TPW, int NKT>
+__global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7, two waves per SIMD
+    const int iw = wave % p.IW, ph = wave / p.IW;                   // item group, pixel-pair range
+    const int li = lane & 31, lh = lane >> 5;
+    const int ct = blockIdx.x % p.ctiles, kg = blockIdx.x / p.ctiles;
+    const int c0 = ct * 32, k0 = kg * 32 * NKT;
+    const int slab = blockIdx.y;
+    const int tile_begin = slab * p.tiles_per_slab;
+    const int tile_end = min(tile_begin + p.tiles_per_slab, p.ntiles_total);
+
+    const int halo_pix = p.HR * p.HC;
+    const int n_img_rows = halo_pix;                    // 128-byte rows: halo pixels, then 128*NKT feature rows
+    const int n_rows = n_img_rows + 128 * NKT;
+    const int n_chunks = (n_rows + 7) >> 3;             // 1 KiB DMA pieces
+    const int buf_floats = n_chunks * 256;
+
+    // (tap, k-tile) items of this wave; surplus slots recompute the last real item into an
+    // accumulator that is never stored (no branches in the MFMA loop)
+    int offA[TPW], offB[TPW], item_tap[TPW], item_kt[TPW];
+    bool item_ok[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        int it = iw * p.ipw + i;
+        item_ok[i] = (i < p.ipw) && (it < p.nitems);
+        if (it >= p.nitems) it = p.nitems - 1;
+        const int tap = it % p.ntaps, kt = it / p.ntaps;
+        item_tap[i] = tap; item_kt[i] = kt;
+        offA[i] = ((tap / p.kw) * p.HC + (tap % p.kw)) * 32 + lh * p.sw * 32 + li;
+        offB[i] = (n_img_rows + kt * 128 + lh) * 32 + li;
+    }
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float sb[NKT];
+#pragma unroll
+    for (int y = 0; y < NKT; ++y) sb[y] = 0.f;
+    const bool do_bias = p.bias_out != nullptr && ct == 0;
+
+    // asynchronous staging of one spatial tile into buffer `buf` (LDS-DMA, no registers)
+    auto stage = [&](int tile, float* buf) {
+        int b = tile;
+        const int tw_i = b % p.tiles_w; b /= p.tiles_w;
+        const int th_i = b % p.tiles_h;
+        const int n = b / p.tiles_h;
+        const int oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
+        const int ih0 = oh0 * p.sh - p.pt, iw0 = ow0 * p.sw - p.pl;
+        const int c4 = lane & 7;
+        for (int chunk = wave; chunk < n_chunks; chunk += 8) {
+            const int row = chunk * 8 + (lane >> 3);
+            const float* src = reinterpret_cast<const float*>(g_zero16);
+            if (row < n_img_rows) {
+                const int hr = row / p.HC, hc = row - hr * p.HC;
+                const int ih = ih0 + hr, iwc = iw0 + hc, ch = c0 + c4 * 4;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iwc < (unsigned)p.W && ch < p.C)
+                    src = p.img + (int64_t)((n * p.H + ih) * p.W + iwc) * p.img_ld + ch;
+            } else if (row < n_rows) {
+                const int j = row - n_img_rows;
+                const int kt = j >> 7, q = j & 127;
+                const int oh = oh0 + (q >> p.tw_shift), ow = ow0 + (q & (p.TW - 1)), kk = k0 + kt * 32 + c4 * 4;
+                if (oh < p.Ho && ow < p.Wo && kk < p.K)
+                    src = p.feat + (int64_t)((n * p.Ho + oh) * p.Wo + ow) * p.feat_ld + kk;
+            }
+            dma16(src, buf + chunk * 256);
+        }
+    };
+
+    const int jshift = p.tw_shift - 1;                       // log2(TW/2)
+    const int jmask = (p.TW >> 1) - 1;
+    const int strideA = 2 * p.sw * 32, rowA = p.sh * p.HC * 32;
+    const int nsteps = 64 / p.PH;                            // pixel pairs of this wave (even)
+    const int s_begin = ph * nsteps;
+
+    if (tile_begin < tile_end) stage(tile_begin, smem);
+    int cur = 0;
+    for (int tile = tile_begin; tile < tile_end; ++tile, cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA pieces have landed
+        __syncthreads();                                        // everyone's have; previous tile fully consumed
+        const float* buf = smem + cur * buf_floats;
+        if (tile + 1 < tile_end) stage(tile + 1, smem + (cur ^ 1) * buf_floats);
+
+        // operands of pixel pair s+1 are read while the MFMAs of pair s run; the last iteration's
+        // look-ahead wraps to the first pair (a harmless extra read) so the loop needs no tail
+        float a0[TPW], b0[TPW], a1[TPW], b1[TPW];
+        auto ld = [&](float (&a)[TPW], float (&b)[TPW], int s) {
+            const float* pa = buf + (s >> jshift) * rowA + (s & jmask) * strideA;
+            const float* pb = buf + s * 64;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { a[i] = pa[offA[i]]; b[i] = pb[offB[i]]; }
+        };
+        auto mma = [&](const float (&a)[TPW], const float (&b)[TPW]) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], acc[i], 0, 0, 0);
+        };
+        ld(a0, b0, s_begin);
+        for (int s = 0; s < nsteps; s += 2) {
+            ld(a1, b1, s_begin + s + 1);
+            mma(a0, b0);
+            ld(a0, b0, s_begin + ((s + 2) & (nsteps - 1)));
+            mma(a1, b1);
+        }
+        if (do_bias && wave == 0) {
+            // bias gradient = column sums of the feature tile (lane = (pixel parity, channel))
+#pragma unroll
+            for (int y = 0; y < NKT; ++y) {
+                const float* pb = buf + (n_img_rows + y * 128 + lh) * 32 + li;
+                float t = 0.f;
+                for (int s = 0; s < 64; ++s) t += pb[s * 64];
+                sb[y] += t;
+            }
+        }
+    }
+
+    // combine the PH pixel-range partials of each item group through LDS (fixed order), then store
+    __syncthreads();
+    for (int r = 1; r < p.PH; ++r) {
+        float* xch = smem + (iw * TPW) * 1024 + lane;            // [item][16 regs][64 lanes]
+        if (ph == r) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) xch[(i * 16 + q) * 64] = acc[i][q];
+        }
+        __syncthreads();
+        if (ph == 0) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][q] += xch[(i * 16 + q) * 64];
+        }
+        __syncthreads();
+    }
+    if (ph == 0) {
+        // partial filter of this workgroup: D layout col (lane&31) = k, row = c
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (!item_ok[i]) continue;
+            float* out = p.out + ((int64_t)slab * p.ntaps + item_tap[i]) * p.C * p.K;
+            const int k = k0 + item_kt[i] * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (c < p.C && k < p.K) out[(int64_t)c * p.K + k] = acc[i][r];
+            }
+        }
+    }
+    if (do_bias && wave == 0) {
+#pragma unroll
+        for (int y = 0; y < NKT; ++y) {
+            const float s = sb[y] + __shfl_xor(sb[y], 32);
+            const int k = k0 + y * 32 + li;
+            if (lh == 0 && k < p.K) p.bias_out[(int64_t)slab * p.K + k] = s;
+        }
+    }
+}
+
+template <int TPW, int NKT>
+static int launch_wgt(const WgTileParams& p, dim3 grid, size_t lds, void* stream, const char* name, const char* who,
+                      double flops, double bytes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tile_kernel<TPW, NKT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
+        wgrad_tile_kernel<TPW, NKT><<<grid, 512, lds, s>>>(p);
+        return launched(who);
+    });
+}
+
+// Plans the tiled kernel for a geometry.  Returns false when the generic filtgrad kernel must be used.
+bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out, int* cfg_out, size_t* lds_out) {
+    if (g->C < 16 || g->C % 4 != 0 || g->K % 4 != 0 || g->img_ld % 4 != 0 || g->feat_ld % 4 != 0) return false;
+    if (g->Ho * g->Wo < 128 || g->Wo < 8) return false;
+    const int ntaps = g->kh * g->kw;
+    // 8 waves = IW item groups x PH pixel ranges; TPW = items per wave (template)
+    int NKT, TPW, IW, PH, cfg;
+    if (ntaps == 25) {
+        if (g->K > 32) { NKT = 2; IW = 8; PH = 1; TPW = 7; cfg = 1; }       // 50 items: 7,7,6,6,6,6,6,6
+        else { NKT = 1; IW = 4; PH = 2; TPW = 7; cfg = 0; }                 // 25 items: 7,6,6,6
+    } else if (ntaps == 9) {
+        if (g->K > 32) { NKT = 2; IW = 4; PH = 2; TPW = 5; cfg = 3; }       // 18 items: 5,5,4,4
+        else { NKT = 1; IW = 2; PH = 4; TPW = 5; cfg = 2; }                 // 9 items: 5,4
+    } else return false;
+    WgTileParams p = {};
+    int ho, wo;
+    same_pad(g->H, g->kh, g->sh, &ho, &p.pt);
+    same_pad(g->W, g->kw, g->sw, &wo, &p.pl);
+    // spatial tile: 128 output pixels, least padded work
+    int64_t best = -1;
+    for (int sh = 3; sh <= 6; ++sh) {
+        const int TW = 1 << sh, TH = 128 / TW;
+        if (TH > g->Ho * 2 || TW > g->Wo * 2) continue;
+        const int th = cdiv(g->Ho, TH), tw = cdiv(g->Wo, TW);
+        const int HR = (TH - 1) * g->sh + g->kh, HC = (TW - 1) * g->sw + g->kw;
+        size_t lds = 2 * (size_t)(((HR * HC + 128 * NKT + 7) / 8) * 1024);
+        lds = std::max(lds, (size_t)IW * TPW * 4096);                       // end-of-kernel partial exchange
+        if (lds > 160 * 1024) continue;
+        const int64_t cost = (int64_t)th * tw * (128 * 64 + HR * HC);
+        if (best < 0 || cost < best) {
+            best = cost;
+            p.TH = TH; p.TW = TW; p.tw_shift = sh; p.tiles_h = th; p.tiles_w = tw; p.HR = HR; p.HC = HC;
+        }
+    }
+    if (best < 0) return false;
+    p.N = g->N; p.H = g->H; p.W = g->W; p.C = g->C; p.img_ld = g->img_ld;
+    p.Ho = g->Ho; p.Wo = g->Wo; p.K = g->K; p.feat_ld = g->feat_ld;
+    p.sh = g->sh; p.sw = g->sw; p.kw = g->kw;
+    p.ntaps = ntaps; p.nitems = ntaps * NKT; p.ipw = cdiv(p.nitems, IW); p.IW = IW; p.PH = PH;
+    (void)TPW;
+    p.ctiles = cdiv(g->C, 32);
+    const int kgroups = cdiv(g->K, 32 * NKT);
+    p.ntiles_total = g->N * p.tiles_h * p.tiles_w;
+    // one workgroup per CU in total (operands are prefetched inside the workgroup)
+    const int blocks_xy = p.ctiles * kgroups;
+    int nslab = std::max(1, 256 / blocks_xy);
+    if (nslab > p.ntiles_total) nslab = p.ntiles_total;
+    p.tiles_per_slab = cdiv(p.ntiles_total, nslab);
+    nslab = cdiv(p.ntiles_total, p.tiles_per_slab);
+    *out = p;
+    *nslab_out = nslab;
+    *cfg_out = cfg;
+    *lds_out = std::max(2 * (size_t)(((p.HR * p.HC + 128 * NKT + 7) / 8) * 1024), (size_t)IW * TPW * 4096);
+    return true;
+}
+
+int wgrad_tile_launch(const mv3d_conv_geom* g, WgTileParams p, int nslab, int cfg, size_t lds, void* stream, const char* who) {
+    const double flops = 2.0 * g->N * g->Ho * g->Wo * g->kh * g->kw * (double)g->C * g->K;
+    const double bytes = 4.0 * ((double)g->N * g->H * g->W * g->C + (double)g->N * g->Ho * g->Wo * g->K + (double)g->kh * g->kw * g->C * g->K);
+    const int NKTv = (cfg & 1) ? 2 : 1;
+    dim3 grid(p.ctiles * cdiv(g->K, 32 * NKTv), nslab);
+    switch (cfg) {
+        case 0: return launch_wgt<7, 1>(p, grid, lds, stream, "wgrad_tile<5x5,K32>", who, flops, bytes);
+        case 1: return launch_wgt<7, 2>(p, grid, lds, stream, "wgrad_tile<5x5,K64>", who, flops, bytes);
+        case 2: return launch_wgt<5, 1>(p, grid, lds, stream, "wgrad_tile<3x3,K32>", who, flops, bytes);
+        default: return launch_wgt<5, 2>(p, grid, lds, stream, "wgrad_tile<3x3,K64>", who, flops, bytes);
+    }
+}
+
+int wgrad_tile_nslab(const mv3d_conv_geom* g) {
+    WgTileParams p; int nslab, cfg; size_t lds;
+    return wgrad_tile_plan(g, &p, &nslab, &cfg, &lds) ? nslab : 0;
+}
+
+int wgrad_tile_launch_erased(const mv3d_conv_geom* g, const void* img, const void* feat, void* out, void* bias_out, void* stream,
+                             const char* who, int* nslab_out) {
+    WgTileParams p; int nslab, cfg; size_t lds;
+    if (!wgrad_tile_plan(g, &p, &nslab, &cfg, &lds)) return fail(MV3D_E_INVAL, "%s: tiled wgrad not applicable", who);
+    p.img = (const float*)img; p.feat = (const float*)feat; p.out = (float*)out; p.bias_out = (float*)bias_out;
+    *nslab_out = nslab;
+    return wgrad_tile_launch(g, p, nslab, cfg, lds, stream, who);
+}
+
+}  // namespace mv3d

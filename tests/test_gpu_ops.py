@@ -36,6 +36,9 @@ CONV_CASES = [  # n, h, w, c, k, ksz, s
     (1, 16, 16, 128, 64, 5, 1),      # d3_0 with 2 decoders (Cout 128 -> here reversed sizes)
     (2, 4, 4, 320, 256, 3, 1),       # fully_conv e4_1 (256+64 in)
     (1, 5, 5, 8, 8, 1, 1),           # 1x1
+    (1, 24, 24, 32, 32, 5, 1),       # halo kernel with tile overhang (24 is not a power of two)
+    (2, 32, 32, 16, 32, 3, 2),       # halo kernel, 16 input channels (half-filled chunk)
+    (1, 40, 24, 48, 80, 3, 1),       # halo kernel, 48 channels in (1.5 chunks), 80 out (N tail)
 ]
 
 
@@ -81,6 +84,8 @@ DECONV_CASES = [  # n, hi, wi, cin(feature side K), cout(image side C), ksz, s
     (1, 3, 5, 8, 6, 5, 2),           # ragged
     (2, 8, 8, 32, 128, 3, 2),        # tinghui d3
     (1, 4, 4, 12, 5, 3, 1),          # stride-1 generic, odd channels
+    (1, 12, 20, 48, 40, 5, 2),       # 4-phase halo kernel with overhang and channel tails
+    (2, 16, 16, 32, 16, 3, 1),       # stride-1 transposed conv through the halo kernel
 ]
 
 
