@@ -81,6 +81,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not bracket launches with HIP events')
     ap.add_argument('--dump-kernels', action='store_true', help='print the per-kernel table to stderr')
+    ap.add_argument('--dump-ops', action='store_true', help='print every launch of the step in order to stderr')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -146,6 +147,9 @@ def main():
         for plan in (g.plan_fwd, g.plan_bwd):
             lib.plan_profile_collect(plan)
             for name, fl, by, ms, runs in _lib.plan_ops(plan):
+                if args.dump_ops and rank == 0:
+                    m1 = ms / max(runs, 1)
+                    print("%-34s %9.1f us  %8.3f GFLOP %8.1f MB  %7.1f TF/s %7.0f GB/s" % (name, m1 * 1e3, fl / 1e9, by / 1e6, fl / max(m1, 1e-9) / 1e9, by / max(m1, 1e-9) / 1e6), file=sys.stderr)
                 k = kern.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
                 k['launches'] += 1
                 k['flops'] += fl

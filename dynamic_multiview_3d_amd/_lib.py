@@ -98,7 +98,8 @@ class _Lib:
         for name, (res, args) in OTHER_FUNCS.items():
             fn = getattr(self.dll, name)
             fn.restype, fn.argtypes = res, args
-            setattr(self, name[5:], fn)
+            if name[5:] != 'last_error':
+                setattr(self, name[5:], fn)
         for name, args in STATUS_FUNCS.items():
             fn = getattr(self.dll, name)
             fn.restype, fn.argtypes = C.c_int, args

@@ -572,8 +572,8 @@ class Graph:
 
     def allreduce_grads(self):
         if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.dist_group)
+            from .parallel import allreduce_sum_
+            allreduce_sum_(self.grads, self.dist_group)
 
     def apply_adam(self):
         self.lib.adam_step(self.flat_size, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),

@@ -1,0 +1,115 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of
+include/mv3d_hip.h, argument validation works without a device, the model classes build and
+record their launch plans, and the host bookkeeping (variable order, views, fusion) is right."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dynamic_multiview_3d_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from dynamic_multiview_3d_amd import build
+        build.build()
+    return _lib.lib()
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'mv3d_hip.h')).read()
+    declared = set(re.findall(r'\b(mv3d_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'mv3d_plan'}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib.dll, name), "libmv3d_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert b'gfx950' in lib.version()
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.ConvGeom) == 14 * 4
+    assert _lib.Epilogue.bias.offset == 0 and _lib.Epilogue.act.offset == 8
+    assert _lib.Epilogue.gmask_ref.offset == 24 and C.sizeof(_lib.Epilogue) == 40
+
+
+def test_validation_without_device(lib):
+    g = _lib.conv_geom(1, 8, 8, 4, 4, 3, 3, 3, 3)
+    assert lib.raw_conv2d_fwd(C.byref(g), 1, 1, 1, None, None, 0, None) == -4        # MV3D_E_UNSUPPORTED
+    assert 'stride' in lib.last_error()
+    g = _lib.conv_geom(1, 8, 8, 4, 4, 3, 3, 1, 1)
+    g.Ho = 7
+    assert lib.raw_conv2d_fwd(C.byref(g), 1, 1, 1, None, None, 0, None) == -1        # MV3D_E_INVAL
+    assert lib.raw_adam_step(0, 1, 1, 1, 1, 1e-4, .9, .999, 1e-8, .9, .999, 1.0, None) == -1
+    assert lib.raw_plan_end() == -1
+
+
+def test_plan_records_launch_metadata(lib):
+    plan = lib.plan_create()
+    lib.plan_begin(plan)
+    try:
+        g = _lib.conv_geom(2, 64, 64, 32, 32, 5, 5, 1, 1)
+        epi = _lib.epilogue()
+        lib.conv2d_fwd(C.byref(g), 0x1000, 0x2000, 0x3000, C.byref(epi), None, 0, None)
+        lib.adam_step(1024, 0x1000, 0x2000, 0x3000, 0x4000, 1e-4, .9, .999, 1e-8, .9, .999, 1.0, None)
+    finally:
+        lib.plan_end()
+    ops = _lib.plan_ops(plan)
+    assert [o[0] for o in ops][-1] == 'adam' and ops[0][0].startswith('hconv')
+    assert ops[0][1] == 2.0 * 2 * 64 * 64 * 25 * 32 * 32                  # algorithmic FLOPs of the conv
+    assert ops[1][2] == 28.0 * 1024                                       # Adam: 28 B/param
+    lib.plan_destroy(plan)
+
+
+@pytest.mark.parametrize("modname,clsname,nvars,dead", [
+    ("appearance_flow_model", "AppearanceFlowModel", 47, 0),
+    ("highdim_angle", "AppFlowHighDimAngle", 47, 4),
+    ("lowdim_angle", "AppFlowLowDimAngle", 43, 0),
+    ("appearance_flow_tinghui", "AppearanceFlowTinghui", 29, 0),
+])
+def test_models_build_and_record_plans_on_cpu(lib, modname, clsname, nvars, dead):
+    import importlib
+    cls = getattr(importlib.import_module('dynamic_multiview_3d_amd.' + modname), clsname)
+    m = cls({'batch_size': 2, 'learning_rate': 1e-4}, load_tfrec=False, device='cpu')
+    g = m.graph
+    assert len(g.variables) == nvars
+    assert sum(1 for v in g.variables.values() if not v.has_grad) == dead
+    assert g.n_launch_fwd > 15 and g.n_launch_bwd > 30
+    assert m.gen.shape == (2, 128, 128, 3) and m.flow_field.shape == (2, 128, 128, 2)
+    # variable names / order follow the TF scopes of the reference
+    names = list(g.variables)
+    assert names[0] == 'e0/w' and names[1] == 'e0/b' and names[-1] == 'flow_field/w'
+    # initialisers: biases zero, conv weights truncated at 2 sigma (tf_utils.py:74-80)
+    assert float(g.variables['e0/b'].value().abs().max()) == 0.0
+    w = g.variables['e0/w'].value().numpy()
+    std = np.sqrt(2.0 / (w.shape[0] * w.shape[1] * 3))
+    assert np.abs(w).max() <= 2 * std + 1e-6 and 0.7 * std < w.std() < 1.0 * std
+
+
+def test_concat_is_a_view_and_checkpoint_names(lib, tmp_path):
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    m = AppearanceFlowModel({'batch_size': 2, 'learning_rate': 1e-4}, load_tfrec=False, device='cpu')
+    g = m.graph
+    from dynamic_multiview_3d_amd.graph import ViewNode, CopyConcatNode
+    assert not any(isinstance(n, CopyConcatNode) for n in g.nodes)       # tf.concat([e5, a2]) costs no copy
+    assert sum(isinstance(n, ViewNode) for n in g.nodes) == 3            # 2 reshapes + 1 concat
+    sd = g.state_dict()
+    for k in ('fc1/Matrix', 'fc1/Matrix/Adam', 'fc1/Matrix/Adam_1', 'beta1_power', 'beta2_power'):
+        assert k in sd
+    path = str(tmp_path / 'model12000')
+    m.saver.save(None, path)
+    m.saver.restore(None, path)
+    from dynamic_multiview_3d_amd.model_base import iteration_from_checkpoint_name
+    assert iteration_from_checkpoint_name(path) == 12000                 # train.py:99-101
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.Mv3dError, match='no fallback'):
+        _lib.lib()
