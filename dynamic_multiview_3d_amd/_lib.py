@@ -94,6 +94,9 @@ class _Lib:
         if not os.path.exists(path):
             raise Mv3dError("%s not found: build it with `python -m dynamic_multiview_3d_amd.build` "
                             "(hipcc --offload-arch=gfx950); there is no fallback path" % path)
+        # torch must be imported BEFORE the dlopen: it ships its own libamdhip64, and the library has to bind
+        # to that already-loaded HIP runtime (two runtimes in one process = "no ROCm-capable device").
+        import torch  # noqa: F401
         self.dll = C.CDLL(path)
         for name, (res, args) in OTHER_FUNCS.items():
             fn = getattr(self.dll, name)

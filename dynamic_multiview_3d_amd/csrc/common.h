@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <functional>
 #include "../../include/mv3d_hip.h"
 
@@ -31,6 +32,13 @@ inline int launched(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MV3D_E_HIP, "%s: %s", what, hipGetErrorString(e));
     return MV3D_OK;
+}
+
+// MV3D_DISABLE (diagnostics): bit 0 hconv, bit 1 wgrad_tile, bit 2 small_fc, bit 3 hconv 64-px tiles
+static inline int disabled_paths() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MV3D_DISABLE"); v = e ? atoi(e) : 0; }
+    return v;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -306,22 +306,32 @@ __global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
         const int ih = ho * p.sh + tp - p.pt;
         const bool row_ok = (unsigned)ih < (unsigned)p.H;
         if (!row_ok && !do_bias) continue;
-        const float* irow = p.img + (int64_t)((n * p.H + (row_ok ? ih : 0)) * p.W) * p.img_ld + e;
-        const float* frow = p.feat + (int64_t)(row * p.Wo) * p.feat_ld + k0 + li;
-#pragma unroll 4
-        for (int wo = 0; wo < p.Wo; wo += 2) {
-            const int wp = wo + lh;
-            const int iw0 = wp * p.sw + tq - p.pl;
-            const bool a_ok = row_ok && e_ok && wp < p.Wo && (unsigned)(iw0 + eq) < (unsigned)p.W;
-            const float a = a_ok ? irow[(int64_t)iw0 * p.img_ld] : 0.f;
-            float b[NT];
+        const float* irow = p.img + (int64_t)((n * p.H + (row_ok ? ih : 0)) * p.W) * p.img_ld + (e_ok ? e : 0);
+        const float* frow = p.feat + (int64_t)(row * p.Wo) * p.feat_ld + (k_ok[0] ? k0 + li : 0);
+        for (int wo = 0; wo < p.Wo; wo += 8) {
+            // 4 pixel pairs per trip: all loads first (independent, clamped + masked), then the MFMAs
+            float a[4], b[4][NT];
 #pragma unroll
-            for (int y = 0; y < NT; ++y) b[y] = (wp < p.Wo && k_ok[y]) ? frow[(int64_t)wp * p.feat_ld + y * 32] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int wp = wo + 2 * u + lh;
+                const int iw0 = wp * p.sw + tq - p.pl;
+                const bool a_ok = row_ok && e_ok && wp < p.Wo && (unsigned)(iw0 + eq) < (unsigned)p.W;
+                const float av = irow[a_ok ? (int64_t)iw0 * p.img_ld : 0];
+                a[u] = a_ok ? av : 0.f;
 #pragma unroll
-            for (int y = 0; y < NT; ++y) {
-                acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[y], acc[y], 0, 0, 0);
-                sb[y] += b[y];
+                for (int y = 0; y < NT; ++y) {
+                    const bool b_ok = wp < p.Wo && k_ok[y];
+                    const float bv = frow[b_ok ? (int64_t)wp * p.feat_ld + y * 32 : 0];
+                    b[u][y] = b_ok ? bv : 0.f;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int y = 0; y < NT; ++y) {
+                    acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][y], acc[y], 0, 0, 0);
+                    sb[y] += b[u][y];
+                }
         }
     }
     float* out = p.out + ((int64_t)slab * p.ntap + tap) * p.Cf * p.K;
@@ -344,10 +354,14 @@ __global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
 // elements x 16 slab lanes: each thread adds every 16th slab (independent loads in flight), the 16
 // lanes of an element are combined through LDS.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, int nslab, int64_t count,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, const float* __restrict__ part2,
+                                                          int64_t count2, float* __restrict__ out2, int blocks1) {
+    // two segments in one launch: the filter partials and (optionally) the bias partials
     __shared__ float s_sum[16][17];
+    int blk = blockIdx.x;
+    if (blk >= blocks1) { blk -= blocks1; part = part2; count = count2; out = out2; }
     const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int64_t i = (int64_t)blockIdx.x * 16 + e;
+    const int64_t i = (int64_t)blk * 16 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < count) {
         int k = sl;
@@ -368,6 +382,55 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         out[i] = t;
     }
 }
+
+static int dispatch_reduce(void* stream, const float* part, int nslab, int64_t fcount, float* df, const float* bpart, int K, float* db) {
+    const int blocks1 = (int)cdiv64(fcount, 16);
+    const int blocks2 = (db && bpart) ? cdiv(K, 16) : 0;
+    return dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * ((double)fcount + (blocks2 ? K : 0)) * (nslab + 1)}, [=](hipStream_t s) {
+        reduce_slabs_kernel<<<blocks1 + blocks2, 256, 0, s>>>(part, nslab, fcount, df, bpart, K, db, blocks1);
+        return launched("reduce_slabs_kernel");
+    });
+}
+
+// ---- tiny linear layers (the angle MLP a0/a1/a2: 2->64->64->64, tf_utils.py:54-67): one thread per
+// output element; an MFMA tile pipeline costs ~15 us of pure latency for ~0.5 MFLOP.
+__global__ __launch_bounds__(256) void small_fc_fwd_kernel(int B, int in, int out, const float* x, int x_ld, const float* M,
+                                                          float* y, int y_ld, const IgemmParams ep) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * out) return;
+    const int b = idx / out, o = idx - b * out;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < in; ++i) acc = fmaf(x[(int64_t)b * x_ld + i], M[(int64_t)i * out + o], acc);
+    y[(int64_t)b * y_ld + o] = epilogue_value(ep, acc, b, o);
+}
+__global__ __launch_bounds__(256) void small_fc_dgrad_kernel(int B, int in, int out, const float* dy, int dy_ld, const float* M,
+                                                            float* dx, int dx_ld, const IgemmParams ep) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * in) return;
+    const int b = idx / in, i = idx - b * in;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < out; ++o) acc = fmaf(dy[(int64_t)b * dy_ld + o], M[(int64_t)i * out + o], acc);
+    dx[(int64_t)b * dx_ld + i] = epilogue_value(ep, acc, b, i);
+}
+__global__ __launch_bounds__(256) void small_fc_wgrad_kernel(int B, int in, int out, const float* x, int x_ld, const float* dy,
+                                                            int dy_ld, float* dM, float* db) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (in + 1) * out) return;
+    const int i = idx / out, o = idx - i * out;
+    float acc = 0.f;
+    if (i < in) {
+#pragma unroll 8
+        for (int b = 0; b < B; ++b) acc = fmaf(x[(int64_t)b * x_ld + i], dy[(int64_t)b * dy_ld + o], acc);
+        dM[(int64_t)i * out + o] = acc;
+    } else if (db) {
+#pragma unroll 8
+        for (int b = 0; b < B; ++b) acc += dy[(int64_t)b * dy_ld + o];
+        db[o] = acc;
+    }
+}
+static inline bool is_small_fc(int B, int in, int out) { return !(disabled_paths() & 4) && in <= 256 && out <= 256 && (int64_t)B * (in + out) <= (1 << 16); }
 
 // ------------------------------------------------------------------------------------------------ host side
 static int check_geom(const mv3d_conv_geom* g, const char* who) {
@@ -648,15 +711,7 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
             int ns = 0;
             rc = wgrad_tile_launch_erased(g, img, feat, part, bpart, stream, who, &ns);
             if (rc != MV3D_OK || ns == 1) return rc;
-            rc = dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)fcount * (ns + 1)}, [=](hipStream_t s) {
-                reduce_slabs_kernel<<<(int)cdiv64(fcount, 16), 256, 0, s>>>(part, ns, fcount, dfp);
-                return launched("reduce_slabs_kernel");
-            });
-            if (rc != MV3D_OK || !dbp) return rc;
-            return dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)K * (ns + 1)}, [=](hipStream_t s) {
-                reduce_slabs_kernel<<<cdiv(K, 16), 256, 0, s>>>(bpart, ns, K, dbp);
-                return launched("reduce_slabs_kernel");
-            });
+            return dispatch_reduce(stream, part, ns, fcount, dfp, bpart, K, dbp);
         }
     }
     FiltgradParams p = {};
@@ -679,15 +734,7 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
         return launched(who);
     });
     if (rc != MV3D_OK || nslab == 1) return rc;
-    rc = dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)fcount * (nslab + 1)}, [=](hipStream_t s) {
-        reduce_slabs_kernel<<<(int)cdiv64(fcount, 16), 256, 0, s>>>(p.out, nslab, fcount, dfp);
-        return launched("reduce_slabs_kernel");
-    });
-    if (rc != MV3D_OK || !dbp) return rc;
-    return dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * (double)K * (nslab + 1)}, [=](hipStream_t s) {
-        reduce_slabs_kernel<<<cdiv(K, 16), 256, 0, s>>>(p.bias_out, nslab, K, dbp);
-        return launched("reduce_slabs_kernel");
-    });
+    return dispatch_reduce(stream, p.out, nslab, fcount, dfp, p.bias_out, K, dbp);
 }
 
 }  // namespace mv3d
@@ -765,16 +812,40 @@ static void fc_geom(mv3d_conv_geom& g, int B, int in, int out, int x_ld, int y_l
 int mv3d_fc_fwd(int B, int in, int out, const void* x, int x_ld, const void* M, void* y, int y_ld,
                 const mv3d_epilogue* epi, void* ws, size_t wsb, void* stream) {
     mv3d_conv_geom g; fc_geom(g, B, in, out, x_ld, y_ld);
+    if (B > 0 && in > 0 && out > 0 && x && M && y && is_small_fc(B, in, out)) {
+        int rc = check_epilogue(epi, "mv3d_fc_fwd");
+        if (rc != MV3D_OK) return rc;
+        IgemmParams ep = {}; fill_epilogue(ep, epi);
+        return dispatch(stream, OpInfo{"small_fc_fwd", 2.0 * B * in * out, 4.0 * (B * in + in * out + B * out)}, [=](hipStream_t s) {
+            small_fc_fwd_kernel<<<cdiv(B * out, 256), 256, 0, s>>>(B, in, out, (const float*)x, x_ld, (const float*)M, (float*)y, y_ld, ep);
+            return launched("small_fc_fwd_kernel");
+        });
+    }
     return img2feat(&g, x, M, y, epi, ws, wsb, stream, "mv3d_fc_fwd");
 }
 int mv3d_fc_dgrad(int B, int in, int out, const void* dy, int dy_ld, const void* M, void* dx, int dx_ld,
                   const mv3d_epilogue* epi, void* ws, size_t wsb, void* stream) {
     mv3d_conv_geom g; fc_geom(g, B, in, out, dx_ld, dy_ld);
+    if (B > 0 && in > 0 && out > 0 && dy && M && dx && is_small_fc(B, in, out)) {
+        int rc = check_epilogue(epi, "mv3d_fc_dgrad");
+        if (rc != MV3D_OK) return rc;
+        IgemmParams ep = {}; fill_epilogue(ep, epi);
+        return dispatch(stream, OpInfo{"small_fc_dgrad", 2.0 * B * in * out, 4.0 * (B * in + in * out + B * out)}, [=](hipStream_t s) {
+            small_fc_dgrad_kernel<<<cdiv(B * in, 256), 256, 0, s>>>(B, in, out, (const float*)dy, dy_ld, (const float*)M, (float*)dx, dx_ld, ep);
+            return launched("small_fc_dgrad_kernel");
+        });
+    }
     return feat2img(&g, dy, M, dx, epi, ws, wsb, stream, "mv3d_fc_dgrad");
 }
 int mv3d_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* dM, void* db,
                   void* ws, size_t wsb, void* stream) {
     mv3d_conv_geom g; fc_geom(g, B, in, out, x_ld, dy_ld);
+    if (B > 0 && in > 0 && out > 0 && x && dy && dM && is_small_fc(B, in, out)) {
+        return dispatch(stream, OpInfo{"small_fc_wgrad", 2.0 * B * in * out, 4.0 * (B * in + in * out + B * out)}, [=](hipStream_t s) {
+            small_fc_wgrad_kernel<<<cdiv((in + 1) * out, 256), 256, 0, s>>>(B, in, out, (const float*)x, x_ld, (const float*)dy, dy_ld, (float*)dM, (float*)db);
+            return launched("small_fc_wgrad_kernel");
+        });
+    }
     return filtgrad(&g, x, dy, dM, db, ws, wsb, stream, "mv3d_fc_wgrad");
 }
 size_t mv3d_fc_workspace_bytes(int B, int in, int out) {

@@ -16,6 +16,7 @@
 #include "conv_common.h"
 #include <algorithm>
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace mv3d {
 
@@ -37,10 +38,11 @@ struct Frags {
     float b[16][NT];
 };
 
-template <int NPH, int MT, int NT, bool KMAJOR>
-__global__ __launch_bounds__(256) void hconv_kernel(const IgemmParams p, const HconvExtra x) {
+template <int NPH, int MT, int NT, bool KMAJOR, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, const HconvExtra x) {
     extern __shared__ __attribute__((aligned(16))) float halo[];
     constexpr int CS = 33;
+    constexpr int NTHR = WAVES * 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -124,11 +126,11 @@ __global__ __launch_bounds__(256) void hconv_kernel(const IgemmParams p, const H
         if (cc) __syncthreads();
         // halo staging in batches of 8 independent 16-byte loads per thread (all in flight
         // together), then the LDS stores; out-of-image pixels load a valid dummy address and are zeroed
-        for (int base = 0; base < halo_pix * 8; base += 256 * 8) {
+        for (int base = 0; base < halo_pix * 8; base += NTHR * 8) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256 + tid;
+                const int idx = base + u * NTHR + tid;
                 const int pix = idx >> 3, c4 = idx & 7;
                 const int hr = pix / x.HC, hc = pix - hr * x.HC;
                 const int ih = ih0 + hr, iw = iw0 + hc;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void hconv_kernel(const IgemmParams p, const H
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * 256 + tid;
+                const int idx = base + u * NTHR + tid;
                 if (idx < halo_pix * 8) {
                     float* d = halo + (idx >> 3) * CS + (idx & 7) * 4;
                     d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
@@ -199,17 +201,17 @@ __global__ __launch_bounds__(256) void hconv_kernel(const IgemmParams p, const H
     }
 }
 
-template <int NPH, int MT, int NT, bool KMAJOR>
+template <int NPH, int MT, int NT, bool KMAJOR, int WAVES>
 static int launch_hconv(const IgemmParams& p, const HconvExtra& x, dim3 grid, size_t lds, void* stream, const char* name,
                         const char* who, double flops, double bytes) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<NPH, MT, NT, KMAJOR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<NPH, MT, NT, KMAJOR, WAVES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
-        hconv_kernel<NPH, MT, NT, KMAJOR><<<grid, 256, lds, s>>>(p, x);
+        hconv_kernel<NPH, MT, NT, KMAJOR, WAVES><<<grid, WAVES * 64, lds, s>>>(p, x);
         return launched(who);
     });
 }
@@ -235,30 +237,49 @@ static bool pick_tile(const IgemmParams& p, int PIX, int Hp, int Wp, int dh_span
 
 int try_hconv(const IgemmParams& p, void* stream, const char* who, double flops, double bytes) {
     const int nph = p.so_h * p.so_w;
+    if (disabled_paths() & 1) return 1;
     if (p.fold || (nph != 1 && nph != 4)) return 1;
     if (p.Ka % 16 != 0 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15)) return 1;
     const bool kmajor = (p.w_ns == 1);
     if (!kmajor && ((p.w_ns % 4) != 0 || (reinterpret_cast<uintptr_t>(p.Wt) & 15))) return 1;
     const int Hp = p.Hp[0], Wp = p.Wp[0];
     if (nph == 4 && (p.Hp[1] != Hp || p.Wp[1] != Wp)) return 1;
-    if (Hp * Wp < 128 || Wp < 8) return 1;
+    if (Hp * Wp < 64 || Wp < 8) return 1;
     if (p.Cc < 16) return 1;
     const int ntaps = p.tap_begin[nph];
-    if (ntaps < 1) return 1;
+    if (ntaps < 2) return 1;                      // 1x1 (fc layers): no halo reuse to exploit
     for (int ph = 0; ph < nph; ++ph) if (p.tap_begin[ph + 1] == p.tap_begin[ph]) return 1;
     int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
     for (int t = 0; t < ntaps; ++t) {
         dh_min = std::min<int>(dh_min, p.taps[t].dh); dh_max = std::max<int>(dh_max, p.taps[t].dh);
         dw_min = std::min<int>(dw_min, p.taps[t].dw); dw_max = std::max<int>(dw_max, p.taps[t].dw);
     }
-    const int NT = (p.Cc > 32) ? 2 : 1;
-    if (nph == 4 && NT == 2) return 1;            // 128 accumulator registers + operands: not instantiated
-    // 256-pixel tiles (2 pixel groups per wave) halve the per-tap operand traffic and overhead;
-    // used when the bigger halo still lets two workgroups share a CU's LDS.
+    // Configuration ladder, biggest tile first; step down while the launch would leave CUs idle.
+    //   256 px (2 pixel groups per wave): halves per-tap operand traffic; needs a halo <= 78 KB so
+    //   that two workgroups still share a CU.   64 px (2 waves): for layers with few pixels.
+    struct Cand { int pix, MT, NT, WAVES; size_t cap; };
+    const int ntmax = (p.Cc > 32 && nph == 1) ? 2 : 1;
+    const Cand ladder[4] = {{256, 2, 1, 4, 78 * 1024}, {128, 1, ntmax, 4, 150 * 1024}, {128, 1, 1, 4, 150 * 1024}, {64, 1, 1, 2, 150 * 1024}};
     HconvExtra best = {};
-    int MT = 1;
-    if (nph == 1 && NT == 1 && Hp * Wp >= 256 && pick_tile(p, 256, Hp, Wp, dh_max - dh_min + 1, dw_max - dw_min + 1, 78 * 1024, &best)) MT = 2;
-    else if (!pick_tile(p, 128, Hp, Wp, dh_max - dh_min + 1, dw_max - dw_min + 1, 150 * 1024, &best)) return 1;
+    int MT = 0, NT = 1, WAVES = 4;
+    const int dh_span = dh_max - dh_min + 1, dw_span = dw_max - dw_min + 1;
+    for (int c = 0; c < 4; ++c) {
+        const Cand& cd = ladder[c];
+        if (cd.pix == 64 && (disabled_paths() & 8)) continue;
+        if (cd.pix == 256 && (nph != 1 || ntmax != 1 || Hp * Wp < 256)) continue;
+        HconvExtra x = {};
+        if (!pick_tile(p, cd.pix, Hp, Wp, dh_span, dw_span, cd.cap, &x)) continue;
+        const int64_t blocks = (int64_t)p.N * x.tiles_h * x.tiles_w * cdiv(p.Cc, 32 * cd.NT);
+        best = x; MT = cd.MT; NT = cd.NT; WAVES = cd.WAVES;
+        if (blocks >= 256) break;                  // at least one workgroup per CU
+    }
+    if (MT == 0) return 1;
+    {   // diagnostics: MV3D_HCONV_SKIP=i falls back to igemm for the i-th eligible call only
+        static int counter = 0;
+        const char* e = getenv("MV3D_HCONV_SKIP");
+        const int idx = counter++;
+        if (e && atoi(e) == idx) { fprintf(stderr, "[mv3d] hconv call %d skipped: %s Ha=%d Ca=%d Cc=%d nph=%d\n", idx, who, p.Ha, p.Ca, p.Cc, nph); return 1; }
+    }
     best.dh_min = dh_min; best.dw_min = dw_min;
     best.chunks = cdiv(p.Ka, 32);
     best.ntaps_total = ntaps;
@@ -267,13 +288,15 @@ int try_hconv(const IgemmParams& p, void* stream, const char* who, double flops,
     dim3 grid(p.N * best.tiles_h * best.tiles_w, cdiv(p.Cc, 32 * NT), 1);
     IgemmParams q = p;
     q.ksplit = 1;
-#define MV3D_HCONV(NPH_, MT_, NT_, KM_, NAME) launch_hconv<NPH_, MT_, NT_, KM_>(q, best, grid, lds, stream, NAME, who, flops, bytes)
+#define MV3D_HCONV(NPH_, MT_, NT_, KM_, W_, NAME) launch_hconv<NPH_, MT_, NT_, KM_, W_>(q, best, grid, lds, stream, NAME, who, flops, bytes)
     if (nph == 1) {
-        if (MT == 2) return kmajor ? MV3D_HCONV(1, 2, 1, true, "hconv<1ph,256px,N32,kmajorB>") : MV3D_HCONV(1, 2, 1, false, "hconv<1ph,256px,N32,nmajorB>");
-        if (NT == 1) return kmajor ? MV3D_HCONV(1, 1, 1, true, "hconv<1ph,128px,N32,kmajorB>") : MV3D_HCONV(1, 1, 1, false, "hconv<1ph,128px,N32,nmajorB>");
-        return kmajor ? MV3D_HCONV(1, 1, 2, true, "hconv<1ph,128px,N64,kmajorB>") : MV3D_HCONV(1, 1, 2, false, "hconv<1ph,128px,N64,nmajorB>");
+        if (MT == 2) return kmajor ? MV3D_HCONV(1, 2, 1, true, 4, "hconv<1ph,256px,N32,kmajorB>") : MV3D_HCONV(1, 2, 1, false, 4, "hconv<1ph,256px,N32,nmajorB>");
+        if (WAVES == 2) return kmajor ? MV3D_HCONV(1, 1, 1, true, 2, "hconv<1ph,64px,N32,kmajorB>") : MV3D_HCONV(1, 1, 1, false, 2, "hconv<1ph,64px,N32,nmajorB>");
+        if (NT == 1) return kmajor ? MV3D_HCONV(1, 1, 1, true, 4, "hconv<1ph,128px,N32,kmajorB>") : MV3D_HCONV(1, 1, 1, false, 4, "hconv<1ph,128px,N32,nmajorB>");
+        return kmajor ? MV3D_HCONV(1, 1, 2, true, 4, "hconv<1ph,128px,N64,kmajorB>") : MV3D_HCONV(1, 1, 2, false, 4, "hconv<1ph,128px,N64,nmajorB>");
     }
-    return kmajor ? MV3D_HCONV(4, 1, 1, true, "hconv<4ph,128px,N32,kmajorB>") : MV3D_HCONV(4, 1, 1, false, "hconv<4ph,128px,N32,nmajorB>");
+    if (WAVES == 2) return kmajor ? MV3D_HCONV(4, 1, 1, true, 2, "hconv<4ph,64px,N32,kmajorB>") : MV3D_HCONV(4, 1, 1, false, 2, "hconv<4ph,64px,N32,nmajorB>");
+    return kmajor ? MV3D_HCONV(4, 1, 1, true, 4, "hconv<4ph,128px,N32,kmajorB>") : MV3D_HCONV(4, 1, 1, false, 4, "hconv<4ph,128px,N32,nmajorB>");
 #undef MV3D_HCONV
 }
 

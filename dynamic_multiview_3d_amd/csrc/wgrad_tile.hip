@@ -219,6 +219,7 @@ static int launch_wgt(const WgTileParams& p, dim3 grid, size_t lds, void* stream
 
 // Plans the tiled kernel for a geometry.  Returns false when the generic filtgrad kernel must be used.
 bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out, int* cfg_out, size_t* lds_out) {
+    if (disabled_paths() & 2) return false;
     if (g->C < 16 || g->C % 4 != 0 || g->K % 4 != 0 || g->img_ld % 4 != 0 || g->feat_ld % 4 != 0) return false;
     if (g->Ho * g->Wo < 128 || g->Wo < 8) return false;
     const int ntaps = g->kh * g->kw;

@@ -30,7 +30,13 @@ class Tape:
     'fc1/Matrix', 'pre_image0/e0/b', ...) to arrays; missing ones are created with the
     reference initialisers from `rng` (tf_utils.py:58-65, 74-80, 91-95)."""
 
-    def __init__(self, variables=None, rng=None, dtype=np.float32):
+    def __init__(self, variables=None, rng=None, dtype=np.float32, sign_override=None):
+        # sign_override: optional list (one entry per activation call, in call order) of sign arrays to
+        # use in the activation's backward instead of sign(x).  lrelu'/relu' are discontinuous at 0,
+        # so a pre-activation within rounding noise of 0 may legitimately get either slope depending
+        # on summation order; parity tests pass the device's pattern for exactly those elements.
+        self.sign_override = sign_override
+        self.act_inputs = []      # pre-activation arrays, in activation call order
         self.vars = OrderedDict() if variables is None else variables
         self.rng = rng
         self.dtype = dtype
@@ -122,7 +128,14 @@ class Tape:
 
     def _absact(self, x, kind, leak=0.2):
         y = Node(ops.absact_fwd(x.v, kind, leak))
-        self._rec([y], lambda: x.acc(ops.absact_bwd(x.v, y.g, kind, leak)))
+        idx = len(self.act_inputs)
+        self.act_inputs.append(x.v)
+        if self.sign_override is not None and self.sign_override[idx] is not None:
+            f1, f2 = ops.act_coeffs(kind, leak)
+            sgn = self.sign_override[idx].astype(x.v.dtype)
+            self._rec([y], lambda: x.acc(y.g * (x.v.dtype.type(f1) + x.v.dtype.type(f2) * sgn)))
+        else:
+            self._rec([y], lambda: x.acc(ops.absact_bwd(x.v, y.g, kind, leak)))
         return y
 
     def lrelu(self, x, leak=0.2, name='lrelu'):

@@ -25,6 +25,30 @@ def _rel(a, b):
     return np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def _activation_pattern_override(model, tape):
+    """lrelu'/relu' jump at 0: a pre-activation that is zero to within summation-order noise can get
+    either slope.  For exactly those elements (|pre| <= 1e-5 of the layer's max) the oracle's reverse
+    pass is told to use the device's activation sign; everywhere else the signs must agree."""
+    from dynamic_multiview_3d_amd.graph import ConvNode, LinearNode
+    acts = [n for n in model.graph.nodes if isinstance(n, (ConvNode, LinearNode)) and n.act in (1, 2)]
+    assert len(acts) == len(tape.act_inputs)
+    override, flips = [], 0
+    for n, pre in zip(acts, tape.act_inputs):
+        out = n.y.value().detach().cpu().numpy().reshape(pre.shape)
+        if n.act == 2:      # relu keeps -0.0 for negative inputs
+            dev_sign = np.where(out > 0, 1.0, np.where(np.signbit(out), -1.0, 0.0))
+        else:
+            dev_sign = np.sign(out)
+        diff = dev_sign != np.sign(pre)
+        if diff.any():
+            assert np.abs(pre[diff]).max() <= 1e-5 * np.abs(pre).max(), "activation sign differs away from zero"
+            flips += int(diff.sum())
+            override.append(np.where(diff, dev_sign, np.sign(pre)))
+        else:
+            override.append(None)
+    return override, flips
+
+
 def _check_model(cls, variant, dead=()):
     conf = {'batch_size': 2, 'learning_rate': 1e-4}
     model = cls(conf, load_tfrec=False, build_loss=True, device='cuda')
@@ -40,6 +64,10 @@ def _check_model(cls, variant, dead=()):
     g.run_forward()
     g.run_backward()
     torch.cuda.synchronize()
+    override, flips = _activation_pattern_override(model, tape)
+    assert flips <= 8, flips
+    if flips:
+        out, grads, tape = omodels.run(builder, {k: v.copy() for k, v in variables.items()}, feeds, sign_override=override)
     assert _rel(model.flow_field.numpy(), out['flow_field']) < 1e-4
     assert _rel(model.warp_pts.numpy(), out['warp_pts']) < 1e-5
     assert _rel(model.gen.numpy(), out['gen']) < 1e-4
@@ -64,11 +92,15 @@ def test_appearance_flow_model_forward_backward():
     losses = [float(model.train_step()) for _ in range(3)]
     np.testing.assert_allclose(losses, ref_losses, rtol=1e-4)
     got = g.get_variables()
-    # Adam's first steps move every weight by ~lr regardless of gradient scale; compare the UPDATE
+    # Adam's first steps move every weight by ~lr * g/|g|: a sign function of tiny gradients, so the
+    # element-wise update is not a stable quantity (bit-exactness of the Adam kernel itself is pinned in
+    # test_gpu_ops.py::test_adam_bit_exact_vs_oracle).  Compare the DIRECTION of the 3-step update.
     for k in ('e0/w', 'fc1/Matrix', 'a3/Matrix', 'd1_0/w', 'flow_field/w', 'a5/b'):
-        upd_ref = ov[k] - variables[k]
-        upd = got[k] - variables[k]
-        assert np.abs(upd - upd_ref).max() < 0.05 * np.abs(upd_ref).max() + 1e-7, k
+        upd_ref = (ov[k] - variables[k]).ravel().astype(np.float64)
+        upd = (got[k] - variables[k]).ravel().astype(np.float64)
+        cos = float(upd @ upd_ref / (np.linalg.norm(upd) * np.linalg.norm(upd_ref)))
+        assert cos > 0.98, (k, cos)
+        assert abs(np.abs(upd).max() / np.abs(upd_ref).max() - 1) < 0.05, k
 
 
 def test_highdim_lowdim_tinghui_variants():
