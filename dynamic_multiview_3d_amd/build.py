@@ -14,6 +14,7 @@ UNITS = {
     "conv.hip": [],
     "hconv.hip": [],
     "wgrad_tile.hip": [],
+    "fc.hip": [],
     "elem.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]

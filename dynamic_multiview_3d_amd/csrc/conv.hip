@@ -455,6 +455,10 @@ static void fill_epilogue(IgemmParams& p, const mv3d_epilogue* e) {
     p.gact = e->gmask_act; p.gleak = e->gmask_leak; p.gref = (const float*)e->gmask_ref; p.g_ld = e->gmask_ld;
 }
 
+static void launch_splitk_epilogue(const IgemmParams& e, int blocks, hipStream_t s) {
+    igemm_splitk_epilogue<<<blocks, 256, 0, s>>>(e);
+}
+
 static int check_epilogue(const mv3d_epilogue* e, const char* who) {
     if (!e) return MV3D_OK;
     if (e->act < 0 || e->act > MV3D_ACT_TANH || e->gmask_act < 0 || e->gmask_act > MV3D_ACT_TANH)
@@ -821,6 +825,10 @@ int mv3d_fc_fwd(int B, int in, int out, const void* x, int x_ld, const void* M, 
             return launched("small_fc_fwd_kernel");
         });
     }
+    if (B > 0 && in > 0 && out > 0 && x && M && y && x_ld >= in && y_ld >= out && check_epilogue(epi, "mv3d_fc_fwd") == MV3D_OK) {
+        int rc = try_fc_stream(false, B, in, out, x, x_ld, M, y, y_ld, epi, ws, wsb, stream, "mv3d_fc_fwd", fill_epilogue, launch_splitk_epilogue);
+        if (rc != 1) return rc;
+    }
     return img2feat(&g, x, M, y, epi, ws, wsb, stream, "mv3d_fc_fwd");
 }
 int mv3d_fc_dgrad(int B, int in, int out, const void* dy, int dy_ld, const void* M, void* dx, int dx_ld,
@@ -835,6 +843,10 @@ int mv3d_fc_dgrad(int B, int in, int out, const void* dy, int dy_ld, const void*
             return launched("small_fc_dgrad_kernel");
         });
     }
+    if (B > 0 && in > 0 && out > 0 && dy && M && dx && dy_ld >= out && dx_ld >= in && check_epilogue(epi, "mv3d_fc_dgrad") == MV3D_OK) {
+        int rc = try_fc_stream(true, B, in, out, dy, dy_ld, M, dx, dx_ld, epi, ws, wsb, stream, "mv3d_fc_dgrad", fill_epilogue, launch_splitk_epilogue);
+        if (rc != 1) return rc;
+    }
     return feat2img(&g, dy, M, dx, epi, ws, wsb, stream, "mv3d_fc_dgrad");
 }
 int mv3d_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* dM, void* db,
@@ -846,11 +858,18 @@ int mv3d_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* d
             return launched("small_fc_wgrad_kernel");
         });
     }
+    if (B > 0 && in > 0 && out > 0 && x && dy && dM && x_ld >= in && dy_ld >= out) {
+        int rc = try_fc_wgrad(B, in, out, x, x_ld, dy, dy_ld, dM, db, stream, "mv3d_fc_wgrad");
+        if (rc != 1) return rc;
+    }
     return filtgrad(&g, x, dy, dM, db, ws, wsb, stream, "mv3d_fc_wgrad");
 }
 size_t mv3d_fc_workspace_bytes(int B, int in, int out) {
     mv3d_conv_geom g; fc_geom(g, B, in, out, in, out);
-    return mv3d_conv_workspace_bytes(&g);
+    size_t a = mv3d_conv_workspace_bytes(&g);
+    a = std::max(a, fc_stream_ws_bytes(B, in, out, false));
+    a = std::max(a, fc_stream_ws_bytes(B, in, out, true));
+    return a;
 }
 
 }  // extern "C"

@@ -39,4 +39,11 @@ __device__ __forceinline__ float epilogue_value(const IgemmParams& p, float v, i
 // halo-tile kernel (caller falls back to the generic igemm).
 int try_hconv(const IgemmParams& p, void* stream, const char* who, double flops, double bytes);
 
+// fc.hip: weight-streaming linear layers; each returns 1 when not applicable
+size_t fc_stream_ws_bytes(int B, int in, int out, bool trans);
+int try_fc_stream(bool trans, int B, int in, int out, const void* x, int x_ld, const void* W, void* y, int y_ld,
+                  const mv3d_epilogue* epi, void* ws, size_t wsb, void* stream, const char* who,
+                  void (*fill_epi)(IgemmParams&, const mv3d_epilogue*), void (*launch_epi)(const IgemmParams&, int, hipStream_t));
+int try_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* dM, void* db, void* stream, const char* who);
+
 }  // namespace mv3d

@@ -25,6 +25,7 @@ struct WgTileParams {
     int Ho, Wo, K, feat_ld;
     int sh, sw, pt, pl, kw;
     int TH, TW, tw_shift, tiles_h, tiles_w, HR, HC;
+    int TPIX;            // output pixels per spatial tile: 128, or 64 when the (stride-2) halo would not fit twice in LDS
     int ntaps, nitems, ipw;
     int IW, PH;          // 8 waves = IW item groups x PH pixel-pair ranges
     int ctiles;
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileParams p) {
     const int tile_end = min(tile_begin + p.tiles_per_slab, p.ntiles_total);
 
     const int halo_pix = p.HR * p.HC;
-    const int n_img_rows = halo_pix;                    // 128-byte rows: halo pixels, then 128*NKT feature rows
-    const int n_rows = n_img_rows + 128 * NKT;
+    const int n_img_rows = halo_pix;                    // 128-byte rows: halo pixels, then TPIX*NKT feature rows
+    const int n_rows = n_img_rows + p.TPIX * NKT;
     const int n_chunks = (n_rows + 7) >> 3;             // 1 KiB DMA pieces
     const int buf_floats = n_chunks * 256;
 
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileParams p) {
         const int tap = it % p.ntaps, kt = it / p.ntaps;
         item_tap[i] = tap; item_kt[i] = kt;
         offA[i] = ((tap / p.kw) * p.HC + (tap % p.kw)) * 32 + lh * p.sw * 32 + li;
-        offB[i] = (n_img_rows + kt * 128 + lh) * 32 + li;
+        offB[i] = (n_img_rows + kt * p.TPIX + lh) * 32 + li;
     }
 
     f32x16 acc[TPW];
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileParams p) {
                     src = p.img + (int64_t)((n * p.H + ih) * p.W + iwc) * p.img_ld + ch;
             } else if (row < n_rows) {
                 const int j = row - n_img_rows;
-                const int kt = j >> 7, q = j & 127;
+                const int kt = j / p.TPIX, q = j - kt * p.TPIX;
                 const int oh = oh0 + (q >> p.tw_shift), ow = ow0 + (q & (p.TW - 1)), kk = k0 + kt * 32 + c4 * 4;
                 if (oh < p.Ho && ow < p.Wo && kk < p.K)
                     src = p.feat + (int64_t)((n * p.Ho + oh) * p.Wo + ow) * p.feat_ld + kk;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileParams p) {
     const int jshift = p.tw_shift - 1;                       // log2(TW/2)
     const int jmask = (p.TW >> 1) - 1;
     const int strideA = 2 * p.sw * 32, rowA = p.sh * p.HC * 32;
-    const int nsteps = 64 / p.PH;                            // pixel pairs of this wave (even)
+    const int nsteps = (p.TPIX >> 1) / p.PH;                 // pixel pairs of this wave (even)
     const int s_begin = ph * nsteps;
 
     if (tile_begin < tile_end) stage(tile_begin, smem);
@@ -151,9 +152,9 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileParams p) {
             // bias gradient = column sums of the feature tile (lane = (pixel parity, channel))
 #pragma unroll
             for (int y = 0; y < NKT; ++y) {
-                const float* pb = buf + (n_img_rows + y * 128 + lh) * 32 + li;
+                const float* pb = buf + (n_img_rows + y * p.TPIX + lh) * 32 + li;
                 float t = 0.f;
-                for (int s = 0; s < 64; ++s) t += pb[s * 64];
+                for (int s = 0; s < (p.TPIX >> 1); ++s) t += pb[s * 64];
                 sb[y] += t;
             }
         }
@@ -221,7 +222,7 @@ static int launch_wgt(const WgTileParams& p, dim3 grid, size_t lds, void* stream
 bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out, int* cfg_out, size_t* lds_out) {
     if (disabled_paths() & 2) return false;
     if (g->C < 16 || g->C % 4 != 0 || g->K % 4 != 0 || g->img_ld % 4 != 0 || g->feat_ld % 4 != 0) return false;
-    if (g->Ho * g->Wo < 128 || g->Wo < 8) return false;
+    if (g->Ho * g->Wo < 64 || g->Wo < 8) return false;
     const int ntaps = g->kh * g->kw;
     // 8 waves = IW item groups x PH pixel ranges; TPW = items per wave (template)
     int NKT, TPW, IW, PH, cfg;
@@ -236,20 +237,23 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     int ho, wo;
     same_pad(g->H, g->kh, g->sh, &ho, &p.pt);
     same_pad(g->W, g->kw, g->sw, &wo, &p.pl);
-    // spatial tile: 128 output pixels, least padded work
+    // spatial tile: 128 output pixels (64 if two stride-2 halos do not fit in LDS), least padded work
     int64_t best = -1;
-    for (int sh = 3; sh <= 6; ++sh) {
-        const int TW = 1 << sh, TH = 128 / TW;
-        if (TH > g->Ho * 2 || TW > g->Wo * 2) continue;
-        const int th = cdiv(g->Ho, TH), tw = cdiv(g->Wo, TW);
-        const int HR = (TH - 1) * g->sh + g->kh, HC = (TW - 1) * g->sw + g->kw;
-        size_t lds = 2 * (size_t)(((HR * HC + 128 * NKT + 7) / 8) * 1024);
-        lds = std::max(lds, (size_t)IW * TPW * 4096);                       // end-of-kernel partial exchange
-        if (lds > 160 * 1024) continue;
-        const int64_t cost = (int64_t)th * tw * (128 * 64 + HR * HC);
-        if (best < 0 || cost < best) {
-            best = cost;
-            p.TH = TH; p.TW = TW; p.tw_shift = sh; p.tiles_h = th; p.tiles_w = tw; p.HR = HR; p.HC = HC;
+    const size_t xchg = (PH > 1) ? (size_t)IW * TPW * 4096 : 0;            // end-of-kernel partial exchange
+    for (int tpix = 128; tpix >= 64 && best < 0; tpix >>= 1) {
+        if ((tpix >> 1) / PH < 2) break;
+        for (int sh = 3; sh <= 6; ++sh) {
+            const int TW = 1 << sh, TH = tpix / TW;
+            if (TH < 1 || TH > g->Ho * 2 || TW > g->Wo * 2) continue;
+            const int th = cdiv(g->Ho, TH), tw = cdiv(g->Wo, TW);
+            const int HR = (TH - 1) * g->sh + g->kh, HC = (TW - 1) * g->sw + g->kw;
+            const size_t lds = std::max(2 * (size_t)(((HR * HC + tpix * NKT + 7) / 8) * 1024), xchg);
+            if (lds > 160 * 1024) continue;
+            const int64_t cost = (int64_t)th * tw * (tpix * 64 + HR * HC);
+            if (best < 0 || cost < best) {
+                best = cost;
+                p.TH = TH; p.TW = TW; p.tw_shift = sh; p.tiles_h = th; p.tiles_w = tw; p.HR = HR; p.HC = HC; p.TPIX = tpix;
+            }
         }
     }
     if (best < 0) return false;
@@ -270,7 +274,7 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     *out = p;
     *nslab_out = nslab;
     *cfg_out = cfg;
-    *lds_out = std::max(2 * (size_t)(((p.HR * p.HC + 128 * NKT + 7) / 8) * 1024), (size_t)IW * TPW * 4096);
+    *lds_out = std::max(2 * (size_t)(((p.HR * p.HC + p.TPIX * NKT + 7) / 8) * 1024), xchg);
     return true;
 }
 
