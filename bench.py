@@ -82,6 +82,8 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not bracket launches with HIP events')
     ap.add_argument('--dump-kernels', action='store_true', help='print the per-kernel table to stderr')
     ap.add_argument('--dump-ops', action='store_true', help='print every launch of the step in order to stderr')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument('--single-device', action='store_true', help='rehearsal: all ranks share GPU 0')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -90,13 +92,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
     from dynamic_multiview_3d_amd import _lib
@@ -126,8 +133,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         g.run_forward()
-        g.run_backward()
-        g.allreduce_grads()
+        if world > 1:
+            g.run_backward_overlapped()
+        else:
+            g.run_backward()
         if timing:
             adam_ev[i][0].record()
         g.apply_adam()

@@ -56,6 +56,7 @@ STATUS_FUNCS = {
     "mv3d_plan_begin": [_vp],
     "mv3d_plan_end": [],
     "mv3d_plan_run": [_vp, _vp],
+    "mv3d_plan_run_range": [_vp, _i, _i, _vp],
     "mv3d_plan_profile": [_vp, _i],
     "mv3d_plan_profile_collect": [_vp],
     "mv3d_plan_profile_reset": [_vp],

@@ -198,6 +198,149 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmParams p
     }
 }
 
+// Stride-2 transposed conv with a thin image side (flow field / rgb / depth / mask heads: 32 -> 1..4
+// channels, tf_utils.py:96 via appearance_flow_model.py:125, main_model.py:77).  HBM/L2-bound
+// (AI ~ 40 flop/B).  One thread owns one position of the input grid and produces the whole S x S
+// block of output pixels from its 3x3 (k=5) / 2x2 (k=3) neighbourhood: every input pixel is loaded
+// once per thread and feeds all phases that use it (tap geometry resolved at compile time), the
+// filters sit in LDS and are read as broadcasts.
+template <int KS, int CC>
+__global__ __launch_bounds__(256) void thin_deconv_s2_kernel(const IgemmParams p) {
+    constexpr int S = 2;
+    constexpr int PT = (KS - S) / 2;                          // TF SAME pad_before for even sizes
+    constexpr int DMIN = -((KS - 1 - PT) / S), DMAX = (S - 1 + PT) / S;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];      // [KS*KS][CC][Ka]
+    const int Ka = p.Ka;
+    for (int i = threadIdx.x; i < KS * KS * CC * Ka; i += 256) {
+        const int t = i / (CC * Ka);
+        const int rem = i - t * CC * Ka;
+        const int c = rem / Ka, k = rem - c * Ka;
+        s_w[i] = p.Wt[(int64_t)t * p.w_tap_stride + (int64_t)c * p.w_ns + (int64_t)k * p.w_ks];
+    }
+    __syncthreads();
+    const int Hp = p.Hp[0], Wp = p.Wp[0];
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= p.N * Hp * Wp) return;
+    const int n = m / (Hp * Wp);
+    const int rem = m - n * (Hp * Wp);
+    const int up = rem / Wp, vp = rem - up * Wp;
+    float acc[S * S][CC];
+#pragma unroll
+    for (int a = 0; a < S * S; ++a)
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[a][c] = 0.f;
+#pragma unroll
+    for (int dh = DMIN; dh <= DMAX; ++dh)
+#pragma unroll
+        for (int dw = DMIN; dw <= DMAX; ++dw) {
+            const int ih = up + dh, iw = vp + dw;
+            if ((unsigned)ih >= (unsigned)p.Ha || (unsigned)iw >= (unsigned)p.Wa) continue;
+            const float* src = p.A + (int64_t)((n * p.Ha + ih) * p.Wa + iw) * p.a_ld;
+            for (int k = 0; k < Ka; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src + k);
+#pragma unroll
+                for (int phh = 0; phh < S; ++phh)
+#pragma unroll
+                    for (int phw = 0; phw < S; ++phw) {
+                        // output row u = S*up + phh reads input row i = up + dh through filter row P = phh + PT - S*dh
+                        constexpr int dummy = 0; (void)dummy;
+                        const int P = phh + PT - S * dh, Q = phw + PT - S * dw;
+                        if (P < 0 || P >= KS || Q < 0 || Q >= KS) continue;      // folds at compile time (all constants)
+                        const float* w = s_w + (P * KS + Q) * CC * Ka + k;
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) {
+                            const float4 wv = *reinterpret_cast<const float4*>(w + c * Ka);
+                            float t = acc[phh * S + phw][c];
+                            t = fmaf(v.x, wv.x, t); t = fmaf(v.y, wv.y, t); t = fmaf(v.z, wv.z, t); t = fmaf(v.w, wv.w, t);
+                            acc[phh * S + phw][c] = t;
+                        }
+                    }
+            }
+        }
+#pragma unroll
+    for (int phh = 0; phh < S; ++phh)
+#pragma unroll
+        for (int phw = 0; phw < S; ++phw) {
+            const int64_t pix = (int64_t)(n * p.Hc + up * S + phh) * p.Wc + vp * S + phw;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) p.Out[pix * p.c_ld + c] = epilogue_value(p, acc[phh * S + phw][c], pix, c);
+        }
+}
+
+// Convolution with a tiny image side (C <= 4: the RGB / depth / mask input layers e0, and the input
+// gradient of the flow / rgb heads): the filter row (kw*C <= 20 contiguous floats of an NHWC row) is
+// folded into the GEMM reduction.  One wave = 32 consecutive output pixels x 32 output channels;
+// both MFMA operands come straight from global memory (A: 4 bytes per lane at a 4*s*C-byte pitch,
+// B: 128-byte filter rows, L1-resident), no LDS.  HBM-bound: the layer moves ~46 MB for 1.3 GFLOP.
+struct SmallCParams {
+    const float* X; const float* Wt; float* Y;
+    int N, H, W, C, Ho, Wo, K, y_ld;
+    int kh, kw, sh, sw, pt, pl;
+    int wtiles;                       // 32-pixel groups per output row
+    IgemmParams ep;                   // epilogue fields only
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void smallc_img2feat_kernel(const SmallCParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    int item = blockIdx.x * 4 + wave;
+    if (item >= p.N * p.Ho * p.wtiles) return;
+    const int wt = item % p.wtiles; item /= p.wtiles;
+    const int ho = item % p.Ho;
+    const int n = item / p.Ho;
+    const int wo = wt * 32 + li;
+    const int Cf = p.kw * p.C;                         // folded reduction length per filter row
+    const int npair = (Cf + 1) >> 1;
+    const int iw0 = wo * p.sw - p.pl;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int y = 0; y < NT; ++y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+    for (int pr = 0; pr < p.kh; ++pr) {
+        const int ih = ho * p.sh + pr - p.pt;
+        const bool row_ok = (unsigned)ih < (unsigned)p.H && wo < p.Wo;
+        const float* xrow = p.X + (int64_t)((n * p.H + (row_ok ? ih : 0)) * p.W) * p.C;
+        const float* wrow = p.Wt + (int64_t)pr * Cf * p.K;
+        float a[10], b[10][NT];
+#pragma unroll
+        for (int kp = 0; kp < 10; ++kp) {
+            if (kp < npair) {
+                const int e = 2 * kp + lh;
+                const int q = e / p.C;
+                const bool ok = row_ok && e < Cf && (unsigned)(iw0 + q) < (unsigned)p.W;
+                const float av = xrow[ok ? (int64_t)iw0 * p.C + e : 0];
+                a[kp] = ok ? av : 0.f;
+                const int ec = e < Cf ? e : Cf - 1;
+#pragma unroll
+                for (int y = 0; y < NT; ++y) {
+                    const int col = y * 32 + li;
+                    b[kp][y] = wrow[(int64_t)ec * p.K + (col < p.K ? col : p.K - 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int kp = 0; kp < 10; ++kp)
+            if (kp < npair) {
+#pragma unroll
+                for (int y = 0; y < NT; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], b[kp][y], acc[y], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int y = 0; y < NT; ++y) {
+        const int col = y * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w2 = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (w2 < p.Wo && col < p.K) {
+                const int64_t pix = (int64_t)(n * p.Ho + ho) * p.Wo + w2;
+                p.Y[pix * p.y_ld + col] = epilogue_value(p.ep, acc[y][r], pix, col);
+            }
+        }
+    }
+}
+
 // feat2img with a thin image side (C <= 4: flow field, rgb / depth / mask heads): one thread per
 // output pixel on the VALU, the phase's filter taps staged once per block in LDS.  These layers are
 // HBM/L2-bound (AI ~ 40 flop/B): padding 2 channels to a 32-wide MFMA tile would multiply the work by 16.
@@ -268,7 +411,7 @@ struct FiltgradParams {
     int rows_total, rows_per_slab;
 };
 
-template <int NT>
+template <int NT, int U>
 __global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -308,11 +451,11 @@ __global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
         if (!row_ok && !do_bias) continue;
         const float* irow = p.img + (int64_t)((n * p.H + (row_ok ? ih : 0)) * p.W) * p.img_ld + (e_ok ? e : 0);
         const float* frow = p.feat + (int64_t)(row * p.Wo) * p.feat_ld + (k_ok[0] ? k0 + li : 0);
-        for (int wo = 0; wo < p.Wo; wo += 8) {
-            // 4 pixel pairs per trip: all loads first (independent, clamped + masked), then the MFMAs
-            float a[4], b[4][NT];
+        for (int wo = 0; wo < p.Wo; wo += 2 * U) {
+            // U pixel pairs per trip: all loads first (independent, clamped + masked), then the MFMAs
+            float a[U], b[U][NT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int wp = wo + 2 * u + lh;
                 const int iw0 = wp * p.sw + tq - p.pl;
                 const bool a_ok = row_ok && e_ok && wp < p.Wo && (unsigned)(iw0 + eq) < (unsigned)p.W;
@@ -326,7 +469,7 @@ __global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int y = 0; y < NT; ++y) {
                     acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][y], acc[y], 0, 0, 0);
@@ -528,6 +671,26 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
         int maxtap = 0;
         for (int ph = 0; ph < p.so_h * p.so_w; ++ph) maxtap = std::max(maxtap, p.tap_begin[ph + 1] - p.tap_begin[ph]);
         size_t lds = (size_t)maxtap * p.Cc * p.Ka * sizeof(float);
+        // stride-2 square-filter heads: all four phases per thread (thin_deconv_s2_kernel)
+        const int ntaps_all = p.tap_begin[p.so_h * p.so_w];
+        const bool s2 = p.so_h == 2 && p.so_w == 2 && (ntaps_all == 25 || ntaps_all == 9) && p.Hc == 2 * p.Ha && p.Wc == 2 * p.Wa &&
+                        p.Hp[0] == p.Ha && p.Wp[0] == p.Wa && !(disabled_paths() & 64);
+        if (s2) {
+            const int KS = ntaps_all == 25 ? 5 : 3;
+            const size_t lds2 = (size_t)KS * KS * p.Cc * p.Ka * sizeof(float);
+            if (lds2 <= 64 * 1024) {
+                const int blocks = cdiv(p.N * p.Ha * p.Wa, 256);
+                p.ksplit = 1;
+                static const char* tn2[4] = {"thin_deconv_s2<1>", "thin_deconv_s2<2>", "thin_deconv_s2<3>", "thin_deconv_s2<4>"};
+                return dispatch(stream, OpInfo{tn2[p.Cc - 1], flops, bytes}, [=](hipStream_t s) {
+#define MV3D_THIN(KS_, CC_) thin_deconv_s2_kernel<KS_, CC_><<<blocks, 256, lds2, s>>>(p)
+                    if (KS == 5) { switch (p.Cc) { case 1: MV3D_THIN(5, 1); break; case 2: MV3D_THIN(5, 2); break; case 3: MV3D_THIN(5, 3); break; default: MV3D_THIN(5, 4); break; } }
+                    else { switch (p.Cc) { case 1: MV3D_THIN(3, 1); break; case 2: MV3D_THIN(3, 2); break; case 3: MV3D_THIN(3, 3); break; default: MV3D_THIN(3, 4); break; } }
+#undef MV3D_THIN
+                    return launched("thin_deconv_s2_kernel");
+                });
+            }
+        }
         if (lds <= 64 * 1024) {
             dim3 grid(cdiv(maxMp, 256), 1, p.so_h * p.so_w);
             p.ksplit = 1;
@@ -607,6 +770,21 @@ static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, voi
     p.tap_begin[0] = 0; p.tap_begin[1] = nt;
     p.w_tap_stride = g->C * g->K; p.w_ks = g->K; p.w_ns = 1;
     fill_epilogue(p, epi);
+    if (p.fold && g->C <= 4 && g->kw * g->C <= 20 && g->K <= 64 && !(disabled_paths() & 64)) {
+        SmallCParams q = {};
+        q.X = (const float*)img; q.Wt = (const float*)w; q.Y = (float*)feat;
+        q.N = g->N; q.H = g->H; q.W = g->W; q.C = g->C; q.Ho = g->Ho; q.Wo = g->Wo; q.K = g->K; q.y_ld = g->feat_ld;
+        q.kh = g->kh; q.kw = g->kw; q.sh = g->sh; q.sw = g->sw; q.pt = pt; q.pl = pl;
+        q.wtiles = cdiv(g->Wo, 32);
+        q.ep = p;
+        const int items = g->N * g->Ho * q.wtiles;
+        const bool two = g->K > 32;
+        return dispatch(stream, OpInfo{two ? "smallc_img2feat<N64>" : "smallc_img2feat<N32>", conv_flops(g), conv_bytes(g)}, [=](hipStream_t s) {
+            if (two) smallc_img2feat_kernel<2><<<cdiv(items, 4), 256, 0, s>>>(q);
+            else smallc_img2feat_kernel<1><<<cdiv(items, 4), 256, 0, s>>>(q);
+            return launched(who);
+        });
+    }
     return run_igemm(p, ws, ws_bytes, stream, who, conv_flops(g), conv_bytes(g));
 }
 
@@ -733,8 +911,9 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
     }
     dim3 grid(cdiv(p.ctiles * p.ktiles * p.ntap, 4), nslab);
     rc = dispatch(stream, OpInfo{NT == 2 ? "filtgrad<NT=2>" : "filtgrad<NT=1>", conv_flops(g), conv_bytes(g)}, [=](hipStream_t s) {
-        if (NT == 2) filtgrad_kernel<2><<<grid, 256, 0, s>>>(p);
-        else filtgrad_kernel<1><<<grid, 256, 0, s>>>(p);
+        const bool wide = p.Wo >= 16;
+        if (NT == 2) { if (wide) filtgrad_kernel<2, 8><<<grid, 256, 0, s>>>(p); else filtgrad_kernel<2, 2><<<grid, 256, 0, s>>>(p); }
+        else { if (wide) filtgrad_kernel<1, 8><<<grid, 256, 0, s>>>(p); else filtgrad_kernel<1, 2><<<grid, 256, 0, s>>>(p); }
         return launched(who);
     });
     if (rc != MV3D_OK || nslab == 1) return rc;

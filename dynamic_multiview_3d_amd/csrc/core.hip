@@ -60,32 +60,42 @@ int mv3d_plan_end(void) {
 }
 int mv3d_plan_size(const mv3d_plan* p) { return p ? (int)p->ops.size() : 0; }
 
-int mv3d_plan_run(mv3d_plan* p, void* stream) {
-    if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run: null plan");
-    if (mv3d::g_rec) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run: cannot run while recording");
+// Launches ops [begin, end) of the plan.  A profiled pass over the whole plan may be issued as several
+// consecutive ranges (data-parallel training interleaves bucket all-reduces): the event pool slot of
+// op i is (pass base + 2i), and the pass is closed when a range ends at the last op.
+int mv3d_plan_run_range(mv3d_plan* p, int begin, int end, void* stream) {
+    if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: null plan");
+    if (mv3d::g_rec) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: cannot run while recording");
+    const int n = (int)p->ops.size();
+    if (begin < 0 || end > n || begin > end) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: bad range [%d, %d) of %d", begin, end, n);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (!p->profile) {
-        for (size_t i = 0; i < p->ops.size(); ++i) {
+        for (int i = begin; i < end; ++i) {
             int rc = p->ops[i].fn(s);
             if (rc != MV3D_OK) return rc;
         }
         return MV3D_OK;
     }
     // profiled run: bracket every launch with HIP events on the launch stream; no host sync here
-    const size_t need = p->used + 2 * p->ops.size();
+    const size_t need = p->used + 2 * (size_t)n;
     while (p->pool.size() < need) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_plan_run: hipEventCreate failed");
         p->pool.push_back(e);
     }
-    for (size_t i = 0; i < p->ops.size(); ++i) {
+    for (int i = begin; i < end; ++i) {
         (void)hipEventRecord(p->pool[p->used + 2 * i], s);
         int rc = p->ops[i].fn(s);
         (void)hipEventRecord(p->pool[p->used + 2 * i + 1], s);
         if (rc != MV3D_OK) return rc;
     }
-    p->used = need;
+    if (end == n) p->used = need;
     return MV3D_OK;
+}
+
+int mv3d_plan_run(mv3d_plan* p, void* stream) {
+    if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run: null plan");
+    return mv3d_plan_run_range(p, 0, (int)p->ops.size(), stream);
 }
 
 int mv3d_plan_profile(mv3d_plan* p, int enable) {

@@ -151,6 +151,9 @@ int mv3d_plan_begin(mv3d_plan* p);
 int mv3d_plan_end(void);
 int mv3d_plan_size(const mv3d_plan* p);
 int mv3d_plan_run(mv3d_plan* p, void* stream);
+/* launches ops [begin, end) only: lets the host interleave other stream work (bucket all-reduces of
+ * the data-parallel path) between segments of the recorded backward sequence */
+int mv3d_plan_run_range(mv3d_plan* p, int begin, int end, void* stream);
 /* Per-launch timing for the roofline report: with profiling enabled, mv3d_plan_run brackets every
  * recorded launch with hipEventRecord on the launch stream (no host synchronisation);
  * mv3d_plan_profile_collect() synchronises once and folds all runs into per-op totals.

@@ -70,6 +70,59 @@ def test_two_rank_gradient_allreduce_equals_global_batch_gradient():
         assert err < 1e-6 * max(scale, 1.0), (rank, err, scale)
 
 
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from dynamic_multiview_3d_amd import parallel
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    parallel.init_from_env('gloo')
+    m = AppearanceFlowModel({'batch_size': 2, 'learning_rate': 1e-4}, load_tfrec=False, device='cpu')
+    g = m.graph
+    m.enable_data_parallel(world)
+    # the recorded kernels cannot run without a GPU: replace the segment launcher, keep the product's
+    # bucket schedule and collectives
+    segments = []
+
+    class FakeLib:
+        def plan_run_range(self, plan, begin, end, stream):
+            segments.append((begin, end))
+    real_lib, g.lib = g.lib, FakeLib()
+    g._stream_ptr = lambda: None
+    gen = torch.Generator().manual_seed(100 + rank)
+    g.grads.copy_(torch.randn(g.flat_size, generator=gen))
+    mine = g.grads.clone()
+    g.run_backward_overlapped()
+    g.lib = real_lib
+    other = torch.randn(g.flat_size, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+    err = float((g.grads - (mine + other)).abs().max())
+    q.put((rank, err, segments, [(e, lo, hi) for e, lo, hi in g.grad_buckets], g.n_launch_bwd, g.flat_size))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce_two_ranks():
+    """The product's bucket schedule (Graph.grad_buckets + run_backward_overlapped) on gloo, world 2:
+    segments partition the backward plan, buckets partition the flat gradient buffer from the end
+    towards the start, and after the exchange every element is the sum over ranks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, err, segments, buckets, nbwd, flat in res:
+        assert err < 1e-5, (rank, err)
+        assert segments[0][0] == 0 and segments[-1][1] == nbwd
+        assert all(a[1] == b[0] for a, b in zip(segments, segments[1:]))
+        assert buckets[0][2] == flat and buckets[-1][1] == 0
+        assert all(a[1] == b[2] for a, b in zip(buckets, buckets[1:]))          # contiguous, descending
+        assert len(buckets) >= 4 and all((hi - lo) * 4 >= 60e6 for _, lo, hi in buckets[:-1])
+
+
 def test_shard_batch():
     from dynamic_multiview_3d_amd.parallel import shard_batch, bucket_views
     assert shard_batch(512, 3, 8) == (192, 256)
