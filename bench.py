@@ -122,26 +122,70 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        model.train_step()
-    timing = not args.no_kernel_timing
-    for plan in (g.plan_fwd, g.plan_bwd):
-        lib.plan_profile_reset(plan)
-        lib.plan_profile(plan, 1 if timing else 0)
-    adam_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if timing else []
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
+    def one_step(adam_events=None):
         g.run_forward()
         if world > 1:
             g.run_backward_overlapped()
         else:
             g.run_backward()
-        if timing:
-            adam_ev[i][0].record()
+        if adam_events is not None:
+            adam_events[0].record()
         g.apply_adam()
-        if timing:
-            adam_ev[i][1].record()
+        if adam_events is not None:
+            adam_events[1].record()
+
+    def collect(kern):
+        for plan in (g.plan_fwd, g.plan_bwd):
+            lib.plan_profile_collect(plan)
+            for name, fl, by, ms, runs in _lib.plan_ops(plan):
+                if runs == 0:
+                    continue
+                if args.dump_ops and rank == 0:
+                    m1 = ms / runs
+                    print("%-34s %9.1f us  %8.3f GFLOP %8.1f MB  %7.1f TF/s %7.0f GB/s" % (name, m1 * 1e3, fl / 1e9, by / 1e6, fl / max(m1, 1e-9) / 1e9, by / max(m1, 1e-9) / 1e6), file=sys.stderr)
+                k = kern.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+                k['launches'] += 1
+                k['flops'] += fl
+                k['bytes'] += by
+                k['ms'] += ms / runs
+
+    timing = not args.no_kernel_timing
+    # ---- warm-up (untimed).  With kernel timing on, every launch of the warm-up steps after the first is
+    # bracketed with HIP events: that gives the per-kernel table and names the dominant kernel.
+    table = collections.OrderedDict()
+    dominant = None
+    if args.warmup > 0:
+        one_step()
+    if timing and args.warmup > 1:
+        for plan in (g.plan_fwd, g.plan_bwd):
+            lib.plan_profile_reset(plan)
+            lib.plan_profile_select(plan, None)
+            lib.plan_profile(plan, 1)
+        wev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.warmup - 1)]
+        for i in range(args.warmup - 1):
+            one_step(wev[i])
+        torch.cuda.synchronize()
+        collect(table)
+        table['adam'] = dict(launches=1, flops=0.0, bytes=28.0 * g.flat_size, ms=sum(a.elapsed_time(b) for a, b in wev) / len(wev))
+        dominant = max(table.items(), key=lambda kv: kv[1]['ms'])[0]
+    else:
+        for _ in range(max(args.warmup - 1, 0)):
+            one_step()
+    # ---- timed region: EXACTLY K steps.  Only the dominant kernel's launches carry events (a handful per
+    # step), so `value` and `roofline` come from the same region.
+    for plan in (g.plan_fwd, g.plan_bwd):
+        lib.plan_profile_reset(plan)
+        if timing and dominant is not None and dominant != 'adam':
+            lib.plan_profile_select(plan, dominant.encode())
+            lib.plan_profile(plan, 1)
+        else:
+            lib.plan_profile(plan, 0)
+    time_adam = timing and dominant == 'adam'
+    adam_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if time_adam else []
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(adam_ev[i] if time_adam else None)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -150,23 +194,16 @@ def main():
         elapsed = float(tt.item())
     loss = float(g.loss_buf[0])
 
-    # ---- per-kernel accounting (rank 0's GPU)
+    # ---- dominant kernel inside the timed region (rank 0's GPU)
     kern = collections.OrderedDict()
-    if timing:
+    if timing and dominant is not None:
+        if time_adam:
+            kern['adam'] = dict(launches=1, flops=0.0, bytes=28.0 * g.flat_size, ms=sum(a.elapsed_time(b) for a, b in adam_ev) / len(adam_ev))
+        else:
+            collect(kern)
         for plan in (g.plan_fwd, g.plan_bwd):
-            lib.plan_profile_collect(plan)
-            for name, fl, by, ms, runs in _lib.plan_ops(plan):
-                if args.dump_ops and rank == 0:
-                    m1 = ms / max(runs, 1)
-                    print("%-34s %9.1f us  %8.3f GFLOP %8.1f MB  %7.1f TF/s %7.0f GB/s" % (name, m1 * 1e3, fl / 1e9, by / 1e6, fl / max(m1, 1e-9) / 1e9, by / max(m1, 1e-9) / 1e6), file=sys.stderr)
-                k = kern.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
-                k['launches'] += 1
-                k['flops'] += fl
-                k['bytes'] += by
-                k['ms'] += ms / max(runs, 1)
             lib.plan_profile(plan, 0)
-        adam_ms = sum(a.elapsed_time(b) for a, b in adam_ev) / len(adam_ev)
-        kern['adam'] = dict(launches=1, flops=0.0, bytes=28.0 * g.flat_size, ms=adam_ms)
+            lib.plan_profile_select(plan, None)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
 
@@ -181,12 +218,8 @@ def main():
                    "launches_per_step": g.n_launch_fwd + g.n_launch_bwd + 1},
         "loss": round(loss, 6),
     }
-    if timing and kern:
-        gpu_ms = sum(k['ms'] for k in kern.values())
-        mfma = {n: k for n, k in kern.items() if k['flops'] > 0}
-        conv_ms = sum(k['ms'] for k in mfma.values())
-        conv_fl = sum(k['flops'] for k in mfma.values())
-        dom_name, dom = max(kern.items(), key=lambda kv: kv[1]['ms'])
+    if timing and kern and dominant in kern:
+        dom_name, dom = dominant, kern[dominant]
         if dom['flops'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -195,21 +228,30 @@ def main():
             ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4)}
+        gpu_ms = sum(k['ms'] for k in table.values())
         roof.update({"launches_per_step": dom['launches'], "avg_launch_ms": round(dom['ms'] / dom['launches'], 5),
-                     "share_of_gpu_time": round(dom['ms'] / gpu_ms, 4), "traffic": None})
+                     "share_of_gpu_time": round(table[dom_name]['ms'] / gpu_ms, 4), "traffic": None,
+                     "measured": "HIP events around this kernel's launches inside the timed region"})
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
-                roof["traffic"] = json.load(open(tfile)).get(dom_name)
+                ent = json.load(open(tfile)).get(dom_name)
+                if ent:      # HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), FETCH_SIZE x2-corrected
+                    roof["traffic"] = ent["hbm_bytes_per_launch"]
+                    roof["algorithmic_bytes_per_launch"] = round(dom['bytes'] / dom['launches'])
             except Exception:
                 pass
         out["roofline"] = roof
-        out["stack"] = {"gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
+        mfma = {n: k for n, k in table.items() if k['flops'] > 0}
+        conv_ms = sum(k['ms'] for k in mfma.values())
+        conv_fl = sum(k['flops'] for k in mfma.values())
+        out["stack"] = {"source": "HIP events around every launch during the warm-up steps",
+                        "gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
                         "mfma_kernels_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                         "mfma_kernels_frac_of_f32_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                         "mfma_kernels_share_of_gpu_time": round(conv_ms / gpu_ms, 4)}
         if args.dump_kernels and rank == 0:
-            for n, k in sorted(kern.items(), key=lambda kv: -kv[1]['ms']):
+            for n, k in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
                 rate = ("%7.1f TF/s" % (k['flops'] / k['ms'] / 1e9)) if k['flops'] > 0 else ("%7.0f GB/s" % (k['bytes'] / k['ms'] / 1e6))
                 print("%-34s launches=%3d  ms/step=%8.4f  %s" % (n, k['launches'], k['ms'], rate), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -59,6 +59,7 @@ STATUS_FUNCS = {
     "mv3d_plan_run_range": [_vp, _i, _i, _vp],
     "mv3d_plan_profile": [_vp, _i],
     "mv3d_plan_profile_collect": [_vp],
+    "mv3d_plan_profile_select": [_vp, C.c_char_p],
     "mv3d_plan_profile_reset": [_vp],
     "mv3d_plan_op_info": [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double),
                           C.POINTER(C.c_double), C.POINTER(C.c_int)],

@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 #include <vector>
 
 struct PlanOp {
@@ -9,6 +10,7 @@ struct PlanOp {
     mv3d::OpInfo info;
     double total_ms;
     int runs;
+    bool selected = true;      // bracketed with events when profiling
 };
 
 struct mv3d_plan {
@@ -30,7 +32,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 bool recording() { return g_rec != nullptr; }
-void record(std::function<int(hipStream_t)> fn, const OpInfo& info) { g_rec->ops.push_back(PlanOp{std::move(fn), info, 0.0, 0}); }
+void record(std::function<int(hipStream_t)> fn, const OpInfo& info) { g_rec->ops.push_back(PlanOp{std::move(fn), info, 0.0, 0, true}); }
 }  // namespace mv3d
 
 extern "C" {
@@ -84,9 +86,10 @@ int mv3d_plan_run_range(mv3d_plan* p, int begin, int end, void* stream) {
         p->pool.push_back(e);
     }
     for (int i = begin; i < end; ++i) {
-        (void)hipEventRecord(p->pool[p->used + 2 * i], s);
+        const bool sel = p->ops[i].selected;
+        if (sel) (void)hipEventRecord(p->pool[p->used + 2 * i], s);
         int rc = p->ops[i].fn(s);
-        (void)hipEventRecord(p->pool[p->used + 2 * i + 1], s);
+        if (sel) (void)hipEventRecord(p->pool[p->used + 2 * i + 1], s);
         if (rc != MV3D_OK) return rc;
     }
     if (end == n) p->used = need;
@@ -109,10 +112,14 @@ int mv3d_plan_profile_collect(mv3d_plan* p) {
     if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_profile_collect: null plan");
     const size_t n = p->ops.size();
     if (n == 0 || p->used == 0) return MV3D_OK;
-    if (hipEventSynchronize(p->pool[p->used - 1]) != hipSuccess)
+    size_t last = n;
+    for (size_t i = 0; i < n; ++i) if (p->ops[i].selected) last = i;
+    if (last == n) { p->used = 0; return MV3D_OK; }
+    if (hipEventSynchronize(p->pool[p->used - 2 * n + 2 * last + 1]) != hipSuccess)
         return mv3d::fail(MV3D_E_HIP, "mv3d_plan_profile_collect: hipEventSynchronize failed");
     for (size_t base = 0; base + 2 * n <= p->used; base += 2 * n)
         for (size_t i = 0; i < n; ++i) {
+            if (!p->ops[i].selected) continue;
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, p->pool[base + 2 * i], p->pool[base + 2 * i + 1]) == hipSuccess) {
                 p->ops[i].total_ms += ms;
@@ -120,6 +127,15 @@ int mv3d_plan_profile_collect(mv3d_plan* p) {
             }
         }
     p->used = 0;
+    return MV3D_OK;
+}
+
+// Restrict event bracketing to the launches whose kernel label equals `name` (NULL = all launches).
+// Timing one kernel costs a handful of events per step, so it can stay on inside a timed region.
+int mv3d_plan_profile_select(mv3d_plan* p, const char* name) {
+    if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_profile_select: null plan");
+    if (p->used) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_profile_select: collect pending runs first");
+    for (auto& o : p->ops) o.selected = (name == nullptr) || (strcmp(o.info.name, name) == 0);
     return MV3D_OK;
 }
 
