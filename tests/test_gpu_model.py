@@ -1,6 +1,8 @@
 """Whole-model parity on the GPU: the HIP graph (through the reference-named model classes)
 against the numpy oracle on the same seeded inputs and identical weights.
 Bar from north_star: outputs within 1e-3 relative fp32; measured agreement is ~1e-5."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -121,3 +123,81 @@ def test_zero_flow_head_reproduces_transposed_input():
     feeds = appflow_feeds(np.random.default_rng(9), 2)
     model.forward(**feeds)
     np.testing.assert_array_equal(model.gen.numpy(), feeds['image0'].transpose(0, 2, 1, 3))
+
+
+def _check_generic(model, builder, feeds, out_names):
+    """forward outputs, loss and every variable gradient of a model vs the oracle graph."""
+    g = model.graph
+    variables = _perturb_biases(g)
+    out, grads, tape = omodels.run(builder, {k: v.copy() for k, v in variables.items()}, feeds)
+    assert list(variables.keys()) == tape.used
+    model.feed(**feeds)
+    g.run_forward()
+    g.run_backward()
+    torch.cuda.synchronize()
+    override, flips = _activation_pattern_override(model, tape)
+    assert flips <= 8, flips
+    if flips:
+        out, grads, tape = omodels.run(builder, {k: v.copy() for k, v in variables.items()}, feeds, sign_override=override)
+    for attr, key in out_names.items():
+        assert _rel(getattr(model, attr).numpy(), out[key]) < 1e-4, attr
+    np.testing.assert_allclose(float(g.loss_buf[0]), float(out['loss']), rtol=2e-5)
+    got = g.get_gradients()
+    assert set(got) == set(grads)
+    worst = max(_rel(got[k], grads[k]) for k in grads)
+    assert worst < 1e-3, worst
+
+
+def test_base_prediction_model_color_and_depth():
+    """SURVEY 8a row a11 (tensorflowdata/cars_colordepth): RGB + depth towers, two tanh decoders."""
+    from dynamic_multiview_3d_amd.main_model import Base_Prediction_Model
+    conf = {'batch_size': 2, 'learning_rate': 1e-4, 'use_color': '', 'use_depth': '', 'depth_lr_factor': 0.1}
+    model = Base_Prediction_Model(conf, load_tfrec=False, device='cuda')
+    assert sum(v.size for v in model.graph.variables.values()) == 70049984
+    f = appflow_feeds(np.random.default_rng(4), 2)
+    f['dimage0'] = f['image0'][..., :1].copy()
+    f['dimage1'] = f['image1'][..., :1].copy()
+    _check_generic(model, omodels.base_prediction_builder(conf), f, {'gen_image1': 'gen_image1', 'gen_dimage1': 'gen_dimage1'})
+
+
+@pytest.mark.parametrize("extra", [
+    {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'gen_sep_images': '', 'fully_conv': ''},
+    {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'predict_target_masks': 0.5},
+    {'use_color': '', 'gen_sep_images': '', 'masked_image_loss': '', 'fully_conv': ''},
+])
+def test_multiobject_appflow(extra):
+    """fc and fully-convolutional bottlenecks, flow + direct decoders, masked loss."""
+    from dynamic_multiview_3d_amd.multiobject_appflow import MultiObjectAppFlow
+    from tests.synth import multiobj_feeds
+    conf = dict(extra, batch_size=2, learning_rate=1e-4)
+    model = MultiObjectAppFlow(conf, load_tfrec=False, device='cuda')
+    f = multiobj_feeds(np.random.default_rng(5), 2)
+    names = {a: a for a in ('gen_image1', 'gen_image1_only0', 'gen_image1_only1', 'gen_depth1', 'gen_depth1_only0',
+                            'gen_depth1_only1', 'gen_image1_mask0', 'gen_image1_mask1') if getattr(model, a) is not None}
+    _check_generic(model, omodels.multiobject_builder(conf), f, names)
+
+
+def test_train_driver_runs_saves_and_resumes(tmp_path):
+    """the train.py loop (inclusive iteration range, final checkpoint, resume
+    iteration parsed from the file name) on a tiny batch."""
+    from dynamic_multiview_3d_amd import train
+    conf_py = tmp_path / 'conf.py'
+    conf_py.write_text(
+        "import os\nfrom lowdim_angle import AppFlowLowDimAngle\n"
+        "configuration = {'experiment_name': 't', 'data_dir': '', 'output_dir': os.path.dirname(os.path.realpath(__file__)) + '/modeldata',\n"
+        "  'num_iterations': 30, 'batch_size': 2, 'learning_rate': 1e-4, 'train_val_split': 0.95, 'model': AppFlowLowDimAngle}\n")
+    model = train.main(['--hyper', str(conf_py)])
+    out = tmp_path / 'modeldata'
+    assert (out / 'model').exists()
+    import json
+    rows = [json.loads(l) for l in open(out / 'train_log.jsonl')]
+    its = [r['itr'] for r in rows if 'training_loss' in r]
+    assert its == [0, 10, 20, 30]                                                  # range(itr_0, num_iterations + 1)
+    losses = [r['training_loss'] for r in rows if 'training_loss' in r]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    sd = torch.load(out / 'model', map_location='cpu')
+    assert 'a0/Matrix/Adam_1' in sd and abs(float(sd['beta1_power']) - 0.9 ** 32) < 1e-6      # 31 steps taken
+    os.replace(out / 'model', out / 'model30')
+    model2 = train.main(['--hyper', str(conf_py), '--pretrained', str(out / 'model30'), '--num_iterations', '33'])
+    rows = [json.loads(l) for l in open(out / 'train_log.jsonl')]
+    assert [r['itr'] for r in rows if 'training_loss' in r][-1] == 30              # resumed at 30: logs itr 30 again
