@@ -707,7 +707,7 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
         }
     }
     {
-        int hrc = try_hconv(p, stream, who, flops, bytes);
+        int hrc = try_hconv(p, ws, ws_bytes, stream, who, flops, bytes);
         if (hrc != 1) return hrc;
     }
     int cfg; dim3 grid;
@@ -984,7 +984,9 @@ size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g) {
         if (b > igemm) igemm = b;
     }
     size_t fg = filtgrad_ws_bytes(g);
-    return igemm > fg ? igemm : fg;
+    size_t filt = (size_t)g->kh * g->kw * g->C * g->K * sizeof(float);     // transposed filter copy for the forward kernel
+    size_t m = igemm > fg ? igemm : fg;
+    return m > filt ? m : filt;
 }
 
 // ---- linear layers as 1x1 "convolutions" over a 1 x B image (tf_utils.py:67) -------------------

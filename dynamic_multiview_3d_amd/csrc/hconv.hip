@@ -20,12 +20,15 @@
 
 namespace mv3d {
 
+static inline bool kmajor_of(const IgemmParams& p) { return p.w_ns == 1; }
+
 struct HconvExtra {
     int TH, TW, tw_shift;
     int tiles_h, tiles_w;
     int HR, HC;
     int dh_min, dw_min;
     int chunks, ntaps_total;
+    int phase_split;     // 1: grid.z = stride phase; each workgroup computes ONE phase (more workgroups for small layers)
     int dbg;   // MV3D_DBG diagnostics: 1 = no halo loads, 8 = skip the tap loop
 };
 
@@ -73,7 +76,11 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
                 for (int r = 0; r < 16; ++r) acc[a][m][y][r] = 0.f;
 
     Frags<MT, NT> f0, f1;
-    const int total_seq = x.chunks * x.ntaps_total;
+    // phase-split launches: this workgroup's taps are [tap_lo, tap_hi) of the flat list
+    const int ph_z = x.phase_split ? (int)blockIdx.z : 0;
+    const int tap_lo = x.phase_split ? p.tap_begin[ph_z] : 0;
+    const int ntaps_here = x.phase_split ? p.tap_begin[ph_z + 1] - tap_lo : x.ntaps_total;
+    const int total_seq = x.chunks * ntaps_here;
 
     // Filter fetch for one (chunk, tap): unconditional loads from clamped (always valid) addresses and
     // NO masking -- a conditional load makes hipcc branch around every load, and a select on the loaded
@@ -81,8 +88,8 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
     // (cdna_hip_programming.md, trap (c)).  Clamping is enough: output columns >= Cc are never
     // stored, and channels >= Ka multiply halo entries that were staged as zeros.
     auto load_b = [&](Frags<MT, NT>& f, int seq) {
-        const int cc = seq / x.ntaps_total;
-        const int t = seq - cc * x.ntaps_total;
+        const int cc = seq / ntaps_here;
+        const int t = tap_lo + seq - cc * ntaps_here;
         const float* wt = p.Wt + (int64_t)p.taps[t].widx * p.w_tap_stride;
         const int cbase = cc * 32 + lh * 16;
         const int cb = cbase < p.Ka ? cbase : 0;
@@ -154,10 +161,10 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
         // current tap's MFMAs run).  The hand-over f0 = f1 is register moves issued behind the last
         // MFMA; a branch-selected ping-pong was tried and makes hipcc bounce the accumulators between
         // AGPRs and VGPRs on every tap.
-        load_a(f1, 0);
+        load_a(f1, tap_lo);
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            const int tb = p.tap_begin[ph], te = (x.dbg & 8) ? p.tap_begin[ph] : p.tap_begin[ph + 1];
+            const int tb = x.phase_split ? tap_lo : p.tap_begin[ph], te = (x.dbg & 8) ? tb : (x.phase_split ? tap_lo + ntaps_here : p.tap_begin[ph + 1]);
             for (int t = tb; t < te; ++t, ++seq) {
 #pragma unroll
                 for (int kp = 0; kp < 16; ++kp) {
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
                     for (int y = 0; y < NT; ++y) f0.b[kp][y] = f1.b[kp][y];
                 }
                 if (seq + 1 < total_seq && !(x.dbg & 2)) load_b(f1, seq + 1);
-                if (t + 1 < x.ntaps_total && !(x.dbg & 4)) load_a(f1, t + 1);
+                if (t + 1 < tap_lo + ntaps_here && !(x.dbg & 4)) load_a(f1, t + 1);
 #pragma unroll
                 for (int kp = 0; kp < 16; ++kp)
 #pragma unroll
@@ -182,7 +189,8 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
     const int Hp = p.Hp[0], Wp = p.Wp[0];
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
-        const int phh = ph / p.so_w, phw = ph % p.so_w;
+        const int phe = x.phase_split ? ph_z : ph;
+        const int phh = phe / p.so_w, phw = phe % p.so_w;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -199,6 +207,250 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
                 }
             }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant for single-phase problems (conv fwd / stride-1 conv dgrad / deconv dgrad) with
+// 5x5 or 3x3 filters -- the bulk of the FLOPs.  Same tile / halo / fragment scheme as hconv_kernel, plus:
+//   * a workgroup walks a list of (tile, channel-chunk) units with TWO halo buffers in LDS; while it
+//     multiplies unit u out of one buffer, unit u+1 streams into the other: every tap issues one
+//     16-byte global load per thread and, two taps later, writes it to LDS (a 3-deep register ring,
+//     the out-of-image mask is applied at the write, never at the load).  No s_waitcnt of the tap loop
+//     has to cover a burst of older loads (vmcnt retires in order), nothing is serial at the unit
+//     boundary except one barrier;
+//   * the tap loop is fully unrolled (NTAPS is a template parameter): the two operand register sets
+//     ping-pong by a compile-time index, there are no register copies and no per-tap branches.
+template <int NTAPS, int MT, int NT, bool KMAJOR, int PF, int WAVES, int B1, int B2, int B3>
+__global__ __launch_bounds__(WAVES * 64) void hconvp_kernel(const IgemmParams p, const HconvExtra x) {
+    extern __shared__ __attribute__((aligned(16))) float halo_all[];
+    constexpr int CS = 33;
+    constexpr int NTHR = WAVES * 64;
+    constexpr int NPH = (B1 >= NTAPS) ? 1 : 4;         // taps [0,B1) phase 0, [B1,B2) phase 1, [B2,B3) 2, [B3,NTAPS) 3
+    constexpr int LPT = (PF + NTAPS - 3) / (NTAPS - 2);       // halo loads issued per tap (all committed by the last tap)
+    constexpr int DLY = 2, RING = DLY + 1;
+    static_assert(((PF + LPT - 1) / LPT) + DLY <= NTAPS, "halo prefetch does not fit in the tap loop");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.y * 32 * NT;
+    const int tiles_per_img = x.tiles_h * x.tiles_w;
+    const int total_tiles = p.N * tiles_per_img;
+    const int halo_f4 = x.HR * x.HC * 8;
+    const int buf_floats = x.HR * x.HC * CS;
+
+    int lane_base[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pidx = (wave * MT + m) * 32 + li;
+        const int tr = pidx >> x.tw_shift, tc = pidx & (x.TW - 1);
+        lane_base[m] = ((tr * p.sa_h) * x.HC + tc * p.sa_w) * CS + lh * 16;
+    }
+
+    f32x16 acc[NPH][MT][NT];
+    Frags<MT, NT> f[2];
+    float4 ring[RING][LPT];
+    bool ring_ok[RING][LPT];
+
+    // (tile, chunk) -> pointer of halo float4 slot `idx` (or null when outside the image / channel range)
+    // halo slot j of this thread: (row, col, channel group) inside the halo, fixed for the whole kernel
+    int slot_hr[PF], slot_hc[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int pix = (j * NTHR + tid) >> 3;
+        slot_hr[j] = pix / x.HC;
+        slot_hc[j] = pix - slot_hr[j] * x.HC;
+    }
+    const int c4 = (tid & 7) * 4;
+    // per-unit origin (wave-uniform): image base row/col of the halo and the channel chunk
+    struct Origin { int n, ih0, iw0, ch0; };
+    auto origin_of = [&](int tile, int cc) {
+        Origin o;
+        o.n = tile / tiles_per_img;
+        const int r = tile - o.n * tiles_per_img;
+        const int th_i = r / x.tiles_w, tw_i = r - th_i * x.tiles_w;
+        o.ih0 = th_i * x.TH * p.sa_h + x.dh_min;
+        o.iw0 = tw_i * x.TW * p.sa_w + x.dw_min;
+        o.ch0 = cc * 32;
+        return o;
+    };
+    auto halo_src = [&](const Origin& o, int j) -> const float* {
+        const int ih = o.ih0 + slot_hr[j], iw = o.iw0 + slot_hc[j], ch = o.ch0 + c4;
+        const bool ok = (j * NTHR + tid) < halo_f4 && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa && ch < p.Ka;
+        return ok ? p.A + (int64_t)((o.n * p.Ha + ih) * p.Wa + iw) * p.a_ld + ch : nullptr;
+    };
+    auto halo_store = [&](float* buf, int j, const float4& v, bool ok) {
+        const int idx = j * NTHR + tid;
+        if (idx < halo_f4) {
+            float* d = buf + (idx >> 3) * CS + (idx & 7) * 4;
+            d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
+        }
+    };
+    auto load_b = [&](Frags<MT, NT>& fr, int cc, int t) {
+        const float* wt = p.Wt + (int64_t)p.taps[t].widx * p.w_tap_stride;
+        const int cbase = cc * 32 + lh * 16;
+        const int cb = cbase < p.Ka ? cbase : 0;
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+            const int col = n0 + y * 32 + li;
+            const int colc = col < p.Cc ? col : p.Cc - 1;
+            if constexpr (KMAJOR) {
+                const float* src = wt + (int64_t)cb * p.w_ks + colc;
+#pragma unroll
+                for (int kp = 0; kp < 16; ++kp) { fr.b[kp][y] = *src; src += p.w_ks; }
+            } else {
+                const float4* src = reinterpret_cast<const float4*>(wt + (int64_t)colc * p.w_ns + cb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = src[j];
+                    fr.b[4 * j][y] = v.x; fr.b[4 * j + 1][y] = v.y; fr.b[4 * j + 2][y] = v.z; fr.b[4 * j + 3][y] = v.w;
+                }
+            }
+        }
+    };
+    auto load_a = [&](Frags<MT, NT>& fr, const float* buf, int t) {
+        const IgemmTap tap = p.taps[t];
+        const int off = ((tap.dh - x.dh_min) * x.HC + (tap.dw - x.dw_min)) * CS;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* ap = buf + lane_base[m] + off;
+#pragma unroll
+            for (int kp = 0; kp < 16; ++kp) fr.a[m][kp] = ap[kp];
+        }
+    };
+
+    int tile = blockIdx.x, cc = 0, cur = 0;
+    if (tile >= total_tiles) return;
+    // first unit: plain staging
+    {
+        const Origin o0 = origin_of(tile, 0);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const float* src = halo_src(o0, j);
+            const float4 v = *reinterpret_cast<const float4*>(src ? src : p.A);
+            halo_store(halo_all, j, v, src != nullptr);
+        }
+    }
+    __syncthreads();
+    while (true) {
+        const float* buf = halo_all + cur * buf_floats;
+        float* nbuf = halo_all + (cur ^ 1) * buf_floats;
+        int ntile = tile, ncc = cc + 1;                        // next unit (wave-uniform)
+        if (ncc == x.chunks) { ncc = 0; ntile = tile + gridDim.x; }
+        const bool has_next = ntile < total_tiles;
+        const Origin on = origin_of(has_next ? ntile : tile, ncc);
+        if (cc == 0) {
+#pragma unroll
+            for (int a = 0; a < NPH; ++a)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int y = 0; y < NT; ++y)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][m][y][r] = 0.f;
+        }
+        load_b(f[0], cc, 0);
+        load_a(f[0], buf, 0);
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            if (has_next) {
+                if (t >= DLY) {
+#pragma unroll
+                    for (int q = 0; q < LPT; ++q)
+                        if ((t - DLY) * LPT + q < PF)
+                            halo_store(nbuf, (t - DLY) * LPT + q, ring[(t - DLY) % RING][q], ring_ok[(t - DLY) % RING][q]);
+                }
+#pragma unroll
+                for (int q = 0; q < LPT; ++q)
+                    if (t * LPT + q < PF) {
+                        const float* src = halo_src(on, t * LPT + q);
+                        ring_ok[t % RING][q] = src != nullptr;
+                        ring[t % RING][q] = *reinterpret_cast<const float4*>(src ? src : p.A);
+                    }
+            }
+            if (t + 1 < NTAPS) {
+                load_b(f[(t + 1) & 1], cc, t + 1);
+                load_a(f[(t + 1) & 1], buf, t + 1);
+            }
+            // keep this tap's loads (operands of tap t+1, halo of the next unit) AHEAD of its MFMAs: left
+            // alone, hipcc sinks them to the end of the block and the next tap opens with s_waitcnt vmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int dummy_ = 0; (void)dummy_;
+            const int PH = (NPH == 1) ? 0 : ((t >= B1) + (t >= B2) + (t >= B3));      // compile-time after unrolling
+#pragma unroll
+            for (int kp = 0; kp < 16; ++kp)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int y = 0; y < NT; ++y)
+                        acc[PH][m][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[t & 1].a[m][kp], f[t & 1].b[kp][y], acc[PH][m][y], 0, 0, 0);
+        }
+        if (cc == x.chunks - 1) {
+            const int n = tile / tiles_per_img;
+            const int r2 = tile - n * tiles_per_img;
+            const int th_i = r2 / x.tiles_w, tw_i = r2 - th_i * x.tiles_w;
+            const int oh0 = th_i * x.TH, ow0 = tw_i * x.TW;
+#pragma unroll
+            for (int a = 0; a < NPH; ++a) {
+                const int phh = a / p.so_w, phw = a % p.so_w;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int y = 0; y < NT; ++y) {
+                        const int col = n0 + y * 32 + li;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int q = (wave * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const int ohp = oh0 + (q >> x.tw_shift), owp = ow0 + (q & (x.TW - 1));
+                            if (ohp < p.Hp[0] && owp < p.Wp[0] && col < p.Cc) {
+                                const int64_t pix = (int64_t)(n * p.Hc + ohp * p.so_h + phh) * p.Wc + owp * p.so_w + phw;
+                                p.Out[pix * p.c_ld + col] = epilogue_value(p, acc[a][m][y][r], pix, col);
+                            }
+                        }
+                    }
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();                 // next buffer complete, this one no longer read
+        tile = ntile; cc = ncc; cur ^= 1;
+    }
+}
+
+// [tap][C][K] -> [tap][K][C]: gives the forward convolution the same reduction-contiguous filter
+// layout the backward-data kernels read natively (16-byte B-fragment loads instead of 16 strided
+// 4-byte loads per tap).  Filters are <= 0.6 MB; one 32x32 LDS tile per workgroup.
+__global__ __launch_bounds__(256) void transpose_filter_kernel(const float* __restrict__ w, float* __restrict__ wt, int C, int K) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = w + (int64_t)tap * C * K;
+    float* dst = wt + (int64_t)tap * C * K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j, k = k0 + tx;
+        tile[ty + 8 * j][tx] = (c < C && k < K) ? src[(int64_t)c * K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + ty + 8 * j, c = c0 + tx;
+        if (k < K && c < C) dst[(int64_t)k * C + c] = tile[tx][ty + 8 * j];
+    }
+}
+
+template <int NTAPS, int MT, int NT, bool KMAJOR, int PF, int WAVES, int B1 = NTAPS, int B2 = NTAPS, int B3 = NTAPS>
+static int launch_hconvp(const IgemmParams& p, const HconvExtra& x, dim3 grid, size_t lds, void* stream, const char* name,
+                         const char* who, double flops, double bytes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hconvp_kernel<NTAPS, MT, NT, KMAJOR, PF, WAVES, B1, B2, B3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
+        hconvp_kernel<NTAPS, MT, NT, KMAJOR, PF, WAVES, B1, B2, B3><<<grid, WAVES * 64, lds, s>>>(p, x);
+        return launched(who);
+    });
 }
 
 template <int NPH, int MT, int NT, bool KMAJOR, int WAVES>
@@ -235,12 +487,12 @@ static bool pick_tile(const IgemmParams& p, int PIX, int Hp, int Wp, int dh_span
     return best_cost >= 0;
 }
 
-int try_hconv(const IgemmParams& p, void* stream, const char* who, double flops, double bytes) {
+int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes) {
     const int nph = p.so_h * p.so_w;
     if (disabled_paths() & 1) return 1;
     if (p.fold || (nph != 1 && nph != 4)) return 1;
     if (p.Ka % 16 != 0 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15)) return 1;
-    const bool kmajor = (p.w_ns == 1);
+    const bool kmajor = kmajor_of(p);
     if (!kmajor && ((p.w_ns % 4) != 0 || (reinterpret_cast<uintptr_t>(p.Wt) & 15))) return 1;
     const int Hp = p.Hp[0], Wp = p.Wp[0];
     if (nph == 4 && (p.Hp[1] != Hp || p.Wp[1] != Wp)) return 1;
@@ -274,6 +526,24 @@ int try_hconv(const IgemmParams& p, void* stream, const char* who, double flops,
         if (blocks >= 256) break;                  // at least one workgroup per CU
     }
     if (MT == 0) return 1;
+    // 4-phase problems with few tiles: one phase per workgroup (grid.z = 4) quadruples the workgroup count;
+    // the small input halo is simply staged once per phase.
+    int phase_split = 0;
+    if (nph == 4) {
+        const int64_t fused_blocks = (int64_t)p.N * best.tiles_h * best.tiles_w * cdiv(p.Cc, 32 * NT);
+        if (fused_blocks < 256 || WAVES == 2) {
+            HconvExtra x128 = {};
+            if (pick_tile(p, 128, Hp, Wp, dh_span, dw_span, 150 * 1024, &x128) &&
+                (int64_t)p.N * x128.tiles_h * x128.tiles_w * cdiv(p.Cc, 32) * 4 >= 256) {
+                best = x128; MT = 1; NT = 1; WAVES = 4;
+            } else {
+                HconvExtra x64 = {};
+                if (!pick_tile(p, 64, Hp, Wp, dh_span, dw_span, 150 * 1024, &x64)) return 1;
+                best = x64; MT = 1; NT = 1; WAVES = 2;
+            }
+            phase_split = 1;
+        }
+    }
     {   // diagnostics: MV3D_HCONV_SKIP=i falls back to igemm for the i-th eligible call only
         static int counter = 0;
         const char* e = getenv("MV3D_HCONV_SKIP");
@@ -283,11 +553,77 @@ int try_hconv(const IgemmParams& p, void* stream, const char* who, double flops,
     best.dh_min = dh_min; best.dw_min = dw_min;
     best.chunks = cdiv(p.Ka, 32);
     best.ntaps_total = ntaps;
+    best.phase_split = phase_split;
     { const char* e = getenv("MV3D_DBG"); best.dbg = e ? atoi(e) : 0; }
     const size_t lds = (size_t)best.HR * best.HC * 33 * sizeof(float);
     dim3 grid(p.N * best.tiles_h * best.tiles_w, cdiv(p.Cc, 32 * NT), 1);
     IgemmParams q = p;
     q.ksplit = 1;
+    if (nph == 1 && WAVES == 4 && (ntaps == 25 || ntaps == 9) && p.so_h == 1 && p.so_w == 1 && 2 * lds <= 160 * 1024 &&
+        !(disabled_paths() & 128)) {
+        // persistent kernel, one workgroup per CU (two halo buffers in LDS)
+        const int pf_need = cdiv(best.HR * best.HC * 8, 256);
+        const int ny = cdiv(p.Cc, 32 * NT);
+        const int tiles_total = p.N * best.tiles_h * best.tiles_w;
+        dim3 pgrid(std::min(tiles_total, std::max(1, 256 / ny)), ny, 1);
+        const size_t lds2 = 2 * lds;
+        bool use_t = false;
+        if (kmajor && p.Ka % 4 == 0 && !(disabled_paths() & 256)) {
+            const size_t wbytes = (size_t)ntaps * p.Ka * p.Cc * sizeof(float);
+            if (ws && ws_bytes >= wbytes && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+                // all taps are dense [Ka][Cc] blocks at widx * w_tap_stride
+                const float* wsrc = p.Wt; float* wdst = (float*)ws;
+                const int C = p.Ka, K = p.Cc;
+                dim3 tg(cdiv(K, 32), cdiv(C, 32), ntaps);
+                int rc = dispatch(stream, OpInfo{"transpose_filter", 0.0, 2.0 * wbytes}, [=](hipStream_t s) {
+                    transpose_filter_kernel<<<tg, 256, 0, s>>>(wsrc, wdst, C, K);
+                    return launched("transpose_filter_kernel");
+                });
+                if (rc != MV3D_OK) return rc;
+                q.Wt = (const float*)ws; q.w_ks = 1; q.w_ns = p.Ka;      // [tap][Cc][Ka]
+                use_t = true;
+            }
+        }
+        const bool kmajor = use_t ? false : ::mv3d::kmajor_of(p);
+#define MV3D_HCONVP(NTAPS_, MT_, NT_, KM_, PF_, W_, NAME) launch_hconvp<NTAPS_, MT_, NT_, KM_, PF_, W_>(q, best, pgrid, lds2, stream, NAME, who, flops, bytes)
+        // 256-pixel tiles run as 8 waves x 32 pixels: two waves per SIMD cover each other's non-MFMA issue slots
+        const int pf8 = cdiv(best.HR * best.HC * 8, 512);
+        if (ntaps == 25) {
+            if (MT == 2 && pf8 <= 9) return kmajor ? MV3D_HCONVP(25, 1, 1, true, 9, 8, "hconvp<5x5,256px,N32,kmajorB>") : MV3D_HCONVP(25, 1, 1, false, 9, 8, "hconvp<5x5,256px,N32,nmajorB>");
+            if (MT == 1 && NT == 1 && pf_need <= 13) return kmajor ? MV3D_HCONVP(25, 1, 1, true, 13, 4, "hconvp<5x5,128px,N32,kmajorB>") : MV3D_HCONVP(25, 1, 1, false, 13, 4, "hconvp<5x5,128px,N32,nmajorB>");
+            if (MT == 1 && NT == 2 && pf_need <= 13) return kmajor ? MV3D_HCONVP(25, 1, 2, true, 13, 4, "hconvp<5x5,128px,N64,kmajorB>") : MV3D_HCONVP(25, 1, 2, false, 13, 4, "hconvp<5x5,128px,N64,nmajorB>");
+            if (MT == 1 && NT == 1 && pf_need <= 23) return kmajor ? MV3D_HCONVP(25, 1, 1, true, 23, 4, "hconvp<5x5,128px,N32,kmajorB,bighalo>") : MV3D_HCONVP(25, 1, 1, false, 23, 4, "hconvp<5x5,128px,N32,nmajorB,bighalo>");
+        } else {
+            if (MT == 2 && pf8 <= 7) return kmajor ? MV3D_HCONVP(9, 1, 1, true, 7, 8, "hconvp<3x3,256px,N32,kmajorB>") : MV3D_HCONVP(9, 1, 1, false, 7, 8, "hconvp<3x3,256px,N32,nmajorB>");
+            if (MT == 1 && NT == 1 && pf_need <= 14) return kmajor ? MV3D_HCONVP(9, 1, 1, true, 14, 4, "hconvp<3x3,128px,N32,kmajorB>") : MV3D_HCONVP(9, 1, 1, false, 14, 4, "hconvp<3x3,128px,N32,nmajorB>");
+            if (MT == 1 && NT == 2 && pf_need <= 14) return kmajor ? MV3D_HCONVP(9, 1, 2, true, 14, 4, "hconvp<3x3,128px,N64,kmajorB>") : MV3D_HCONVP(9, 1, 2, false, 14, 4, "hconvp<3x3,128px,N64,nmajorB>");
+        }
+#undef MV3D_HCONVP
+    }
+    if (nph == 4 && WAVES == 4 && MT == 1 && NT == 1 && !kmajor && (ntaps == 25 || ntaps == 9) && 2 * lds <= 160 * 1024 &&
+        (disabled_paths() & 512)) {          // opt-in (MV3D_DISABLE bit 9): measured slower than two resident workgroups per CU
+        // 4-phase persistent kernel (stride-2 transposed conv / conv dgrad): the phase of every tap is a
+        // compile-time constant (taps are listed phase by phase: 4,6,6,9 for 5x5 and 4,2,2,1 for 3x3)
+        bool layout_ok;
+        if (ntaps == 25) layout_ok = p.tap_begin[1] == 4 && p.tap_begin[2] == 10 && p.tap_begin[3] == 16;
+        else layout_ok = p.tap_begin[1] == 4 && p.tap_begin[2] == 6 && p.tap_begin[3] == 8;
+        const int pf_need = cdiv(best.HR * best.HC * 8, 256);
+        if (layout_ok && pf_need <= 7) {
+            const int ny = cdiv(p.Cc, 32);
+            const int tiles_total = p.N * best.tiles_h * best.tiles_w;
+            dim3 pgrid(std::min(tiles_total, std::max(1, 256 / ny)), ny, 1);
+            const size_t lds2 = 2 * lds;
+            if (ntaps == 25) return launch_hconvp<25, 1, 1, false, 7, 4, 4, 10, 16>(q, best, pgrid, lds2, stream, "hconvp<4ph,5x5,128px,N32>", who, flops, bytes);
+            return launch_hconvp<9, 1, 1, false, 7, 4, 4, 6, 8>(q, best, pgrid, lds2, stream, "hconvp<4ph,3x3,128px,N32>", who, flops, bytes);
+        }
+    }
+    if (phase_split) {
+        dim3 sgrid(p.N * best.tiles_h * best.tiles_w, cdiv(p.Cc, 32), 4);
+        if (WAVES == 4) return kmajor ? launch_hconv<1, 1, 1, true, 4>(q, best, sgrid, lds, stream, "hconv<phase-split,128px,N32,kmajorB>", who, flops, bytes)
+                                      : launch_hconv<1, 1, 1, false, 4>(q, best, sgrid, lds, stream, "hconv<phase-split,128px,N32,nmajorB>", who, flops, bytes);
+        return kmajor ? launch_hconv<1, 1, 1, true, 2>(q, best, sgrid, lds, stream, "hconv<phase-split,64px,N32,kmajorB>", who, flops, bytes)
+                      : launch_hconv<1, 1, 1, false, 2>(q, best, sgrid, lds, stream, "hconv<phase-split,64px,N32,nmajorB>", who, flops, bytes);
+    }
 #define MV3D_HCONV(NPH_, MT_, NT_, KM_, W_, NAME) launch_hconv<NPH_, MT_, NT_, KM_, W_>(q, best, grid, lds, stream, NAME, who, flops, bytes)
     if (nph == 1) {
         if (MT == 2) return kmajor ? MV3D_HCONV(1, 2, 1, true, 4, "hconv<1ph,256px,N32,kmajorB>") : MV3D_HCONV(1, 2, 1, false, 4, "hconv<1ph,256px,N32,nmajorB>");
