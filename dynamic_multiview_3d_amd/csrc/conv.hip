@@ -707,7 +707,16 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
         }
     }
     {
-        int hrc = try_hconv(p, ws, ws_bytes, stream, who, flops, bytes);
+        IgemmParams e = {};
+        int hrc = try_hconv(p, ws, ws_bytes, stream, who, flops, bytes, &e);
+        if (hrc == 2) {
+            const int64_t total = (int64_t)e.N * e.Hc * e.Wc * e.Cc;
+            const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
+            return dispatch(stream, OpInfo{"igemm_splitk_epilogue", 0.0, (double)total * 4.0 * (e.ksplit + 1)}, [=](hipStream_t s) {
+                igemm_splitk_epilogue<<<blocks, 256, 0, s>>>(e);
+                return launched("igemm_splitk_epilogue");
+            });
+        }
         if (hrc != 1) return hrc;
     }
     int cfg; dim3 grid;
@@ -986,6 +995,11 @@ size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g) {
     size_t fg = filtgrad_ws_bytes(g);
     size_t filt = (size_t)g->kh * g->kw * g->C * g->K * sizeof(float);     // transposed filter copy for the forward kernel
     size_t m = igemm > fg ? igemm : fg;
+    // small-image halo kernel: transposed filter copy + up to 16 chunk-split partial copies of an output
+    const size_t big_out = out_img > out_feat ? out_img : out_feat;
+    size_t small = 0;
+    if ((size_t)g->Ho * g->Wo <= 64 || (size_t)g->H * g->W <= 64) small = ((filt + 255) & ~(size_t)255) + 16 * big_out * sizeof(float);
+    m = m > small ? m : small;
     return m > filt ? m : filt;
 }
 

@@ -37,7 +37,9 @@ __device__ __forceinline__ float epilogue_value(const IgemmParams& p, float v, i
 
 // hconv.hip: returns MV3D_OK after dispatching, or 1 if the problem is not eligible for the
 // halo-tile kernel (caller falls back to the generic igemm).
-int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes);
+// returns MV3D_OK after dispatching, 1 when not eligible, 2 when partial sums were written and the caller must
+// run igemm_splitk_epilogue with *epi_out
+int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes, IgemmParams* epi_out);
 
 // fc.hip: weight-streaming linear layers; each returns 1 when not applicable
 size_t fc_stream_ws_bytes(int B, int in, int out, bool trans);

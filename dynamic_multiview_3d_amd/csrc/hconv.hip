@@ -29,6 +29,9 @@ struct HconvExtra {
     int dh_min, dw_min;
     int chunks, ntaps_total;
     int phase_split;     // 1: grid.z = stride phase; each workgroup computes ONE phase (more workgroups for small layers)
+    int G, img_shift;    // small images: a tile is G whole images of 2^img_shift phase-grid pixels (halos stacked vertically)
+    int HRi;             // halo rows per image (HR = G * HRi)
+    int ksplit;          // channel chunks are split over grid.z; raw partial sums go to p.Part, igemm_splitk_epilogue finishes
     int dbg;   // MV3D_DBG diagnostics: 1 = no halo loads, 8 = skip the tap loop
 };
 
@@ -53,16 +56,18 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
     int b = blockIdx.x;
     const int tw_i = b % x.tiles_w; b /= x.tiles_w;
     const int th_i = b % x.tiles_h;
-    const int n = b / x.tiles_h;
+    const int n = (b / x.tiles_h) * x.G;                 // first image of the tile (G whole images when G > 1)
     const int oh0 = th_i * x.TH, ow0 = tw_i * x.TW;
     const int n0 = blockIdx.y * 32 * NT;
+    const int zks = (int)blockIdx.z % x.ksplit;            // chunk-split index; grid.z = phase * ksplit + zks
 
     int lane_base[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int pidx = (wave * MT + m) * 32 + li;
-        const int tr = pidx >> x.tw_shift, tc = pidx & (x.TW - 1);
-        lane_base[m] = ((tr * p.sa_h) * x.HC + tc * p.sa_w) * CS + lh * 16;
+        const int g = pidx >> x.img_shift, pr = pidx & ((1 << x.img_shift) - 1);      // G == 1: img_shift covers the tile
+        const int tr = pr >> x.tw_shift, tc = pr & (x.TW - 1);
+        lane_base[m] = ((g * x.HRi + tr * p.sa_h) * x.HC + tc * p.sa_w) * CS + lh * 16;
     }
 
     f32x16 acc[NPH][MT][NT];
@@ -77,10 +82,11 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
 
     Frags<MT, NT> f0, f1;
     // phase-split launches: this workgroup's taps are [tap_lo, tap_hi) of the flat list
-    const int ph_z = x.phase_split ? (int)blockIdx.z : 0;
+    const int ph_z = x.phase_split ? (int)blockIdx.z / x.ksplit : 0;
     const int tap_lo = x.phase_split ? p.tap_begin[ph_z] : 0;
     const int ntaps_here = x.phase_split ? p.tap_begin[ph_z + 1] - tap_lo : x.ntaps_total;
-    const int total_seq = x.chunks * ntaps_here;
+    const int cc_begin = (x.chunks * zks) / x.ksplit, cc_end = (x.chunks * (zks + 1)) / x.ksplit;
+    const int total_seq = (cc_end - cc_begin) * ntaps_here;
 
     // Filter fetch for one (chunk, tap): unconditional loads from clamped (always valid) addresses and
     // NO masking -- a conditional load makes hipcc branch around every load, and a select on the loaded
@@ -88,8 +94,9 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
     // (cdna_hip_programming.md, trap (c)).  Clamping is enough: output columns >= Cc are never
     // stored, and channels >= Ka multiply halo entries that were staged as zeros.
     auto load_b = [&](Frags<MT, NT>& f, int seq) {
-        const int cc = seq / ntaps_here;
-        const int t = tap_lo + seq - cc * ntaps_here;
+        const int cq = seq / ntaps_here;
+        const int cc = cc_begin + cq;
+        const int t = tap_lo + seq - cq * ntaps_here;
         const float* wt = p.Wt + (int64_t)p.taps[t].widx * p.w_tap_stride;
         const int cbase = cc * 32 + lh * 16;
         const int cb = cbase < p.Ka ? cbase : 0;
@@ -129,8 +136,8 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
     const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = ow0 * p.sa_w + x.dw_min;
     const int halo_pix = x.HR * x.HC;
     int seq = 0;
-    for (int cc = 0; cc < x.chunks; ++cc) {
-        if (cc) __syncthreads();
+    for (int cc = cc_begin; cc < cc_end; ++cc) {
+        if (cc > cc_begin) __syncthreads();
         // halo staging in batches of 8 independent 16-byte loads per thread (all in flight
         // together), then the LDS stores; out-of-image pixels load a valid dummy address and are zeroed
         for (int base = 0; base < halo_pix * 8; base += NTHR * 8) {
@@ -139,11 +146,12 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
             for (int u = 0; u < 8; ++u) {
                 const int idx = base + u * NTHR + tid;
                 const int pix = idx >> 3, c4 = idx & 7;
-                const int hr = pix / x.HC, hc = pix - hr * x.HC;
+                const int hrv = pix / x.HC, hc = pix - hrv * x.HC;
+                const int g = hrv / x.HRi, hr = hrv - g * x.HRi;              // G == 1: g = 0
                 const int ih = ih0 + hr, iw = iw0 + hc;
                 const int ch = cc * 32 + c4 * 4;
-                const bool ok = !(x.dbg & 1) && idx < halo_pix * 8 && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa && ch < p.Ka;
-                const float* src = ok ? p.A + (int64_t)((n * p.Ha + ih) * p.Wa + iw) * p.a_ld + ch : p.A;
+                const bool ok = !(x.dbg & 1) && idx < halo_pix * 8 && n + g < p.N && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa && ch < p.Ka;
+                const float* src = ok ? p.A + (int64_t)(((n + g) * p.Ha + ih) * p.Wa + iw) * p.a_ld + ch : p.A;
                 const float4 t4 = *reinterpret_cast<const float4*>(src);
                 v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -187,6 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
     }
 
     const int Hp = p.Hp[0], Wp = p.Wp[0];
+    const int64_t npix_total = (int64_t)p.N * p.Hc * p.Wc;
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         const int phe = x.phase_split ? ph_z : ph;
@@ -199,10 +208,12 @@ __global__ __launch_bounds__(WAVES * 64) void hconv_kernel(const IgemmParams p, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int q = (wave * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int ohp = oh0 + (q >> x.tw_shift), owp = ow0 + (q & (x.TW - 1));
-                    if (ohp < Hp && owp < Wp && col < p.Cc) {
-                        const int64_t pix = (int64_t)(n * p.Hc + ohp * p.so_h + phh) * p.Wc + owp * p.so_w + phw;
-                        p.Out[pix * p.c_ld + col] = epilogue_value(p, acc[ph][m][y][r], pix, col);
+                    const int g = q >> x.img_shift, qr = q & ((1 << x.img_shift) - 1);
+                    const int ohp = oh0 + (qr >> x.tw_shift), owp = ow0 + (qr & (x.TW - 1));
+                    if (n + g < p.N && ohp < Hp && owp < Wp && col < p.Cc) {
+                        const int64_t pix = (int64_t)((n + g) * p.Hc + ohp * p.so_h + phh) * p.Wc + owp * p.so_w + phw;
+                        if (x.ksplit > 1) p.Part[((int64_t)zks * npix_total + pix) * p.Cc + col] = acc[ph][m][y][r];
+                        else p.Out[pix * p.c_ld + col] = epilogue_value(p, acc[ph][m][y][r], pix, col);
                     }
                 }
             }
@@ -482,21 +493,23 @@ static bool pick_tile(const IgemmParams& p, int PIX, int Hp, int Wp, int dh_span
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             out->TH = TH; out->TW = TW; out->tw_shift = sh; out->tiles_h = th; out->tiles_w = tw; out->HR = HR; out->HC = HC;
+            out->G = 1; out->HRi = HR; out->ksplit = 1;
+            out->img_shift = (PIX == 256) ? 8 : (PIX == 128 ? 7 : 6);
         }
     }
     return best_cost >= 0;
 }
 
-int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes) {
+int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes, IgemmParams* epi_out) {
     const int nph = p.so_h * p.so_w;
     if (disabled_paths() & 1) return 1;
     if (p.fold || (nph != 1 && nph != 4)) return 1;
     if (p.Ka % 16 != 0 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15)) return 1;
-    const bool kmajor = kmajor_of(p);
-    if (!kmajor && ((p.w_ns % 4) != 0 || (reinterpret_cast<uintptr_t>(p.Wt) & 15))) return 1;
+    const bool kmajor_in = kmajor_of(p);
+    if (!kmajor_in && ((p.w_ns % 4) != 0 || (reinterpret_cast<uintptr_t>(p.Wt) & 15))) return 1;
     const int Hp = p.Hp[0], Wp = p.Wp[0];
     if (nph == 4 && (p.Hp[1] != Hp || p.Wp[1] != Wp)) return 1;
-    if (Hp * Wp < 64 || Wp < 8) return 1;
+    if (Hp * Wp < 16 || Wp < 4) return 1;
     if (p.Cc < 16) return 1;
     const int ntaps = p.tap_begin[nph];
     if (ntaps < 2) return 1;                      // 1x1 (fc layers): no halo reuse to exploit
@@ -506,6 +519,66 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
         dh_min = std::min<int>(dh_min, p.taps[t].dh); dh_max = std::max<int>(dh_max, p.taps[t].dh);
         dw_min = std::min<int>(dw_min, p.taps[t].dw); dw_max = std::max<int>(dw_max, p.taps[t].dw);
     }
+    // ---- small images (phase grid of 16..64 pixels: the 8x8 / 4x4 layers around the bottleneck) --------
+    // A tile is G whole images (128 pixels) with their halos stacked; the channel chunks are split over
+    // grid.z so that ~512 workgroups exist (each image-row of the GEMM has only N*Hp*Wp = 1k..4k rows but
+    // K = 576..2304); raw partial sums are finished by igemm_splitk_epilogue in a fixed order.
+    {
+        const int ipx = Hp * Wp;
+        const bool pow2 = (ipx & (ipx - 1)) == 0 && (Wp & (Wp - 1)) == 0;
+        if (ipx <= 64 && ipx >= 16 && pow2 && Wp >= 4 && !(disabled_paths() & 1024)) {
+            HconvExtra x = {};
+            x.G = 128 / ipx; x.TH = Hp; x.TW = Wp; x.tiles_h = 1; x.tiles_w = 1;
+            x.tw_shift = 0; while ((1 << x.tw_shift) < Wp) ++x.tw_shift;
+            x.img_shift = 0; while ((1 << x.img_shift) < ipx) ++x.img_shift;
+            x.HRi = (Hp - 1) * p.sa_h + (dh_max - dh_min + 1);
+            x.HC = (Wp - 1) * p.sa_w + (dw_max - dw_min + 1);
+            x.HR = x.G * x.HRi;
+            x.dh_min = dh_min; x.dw_min = dw_min;
+            x.chunks = cdiv(p.Ka, 32); x.ntaps_total = ntaps;
+            x.phase_split = (nph == 4) ? 1 : 0;
+            x.dbg = 0;
+            const size_t lds = (size_t)x.HR * x.HC * 33 * sizeof(float);
+            const int tiles = cdiv(p.N, x.G), ny = cdiv(p.Cc, 32);
+            const int zph = (nph == 4) ? 4 : 1;
+            if (lds <= 150 * 1024) {
+                IgemmParams q = p;
+                // workspace: [transposed filter copy][split partials]
+                size_t used = 0;
+                bool use_t = false;
+                if (kmajor_in && p.Ka % 4 == 0 && (disabled_paths() & 2048)) {     // opt-in: these launches are latency-bound, the copy costs more than it saves
+                    const size_t wbytes = (size_t)ntaps * p.Ka * p.Cc * sizeof(float);
+                    if (ws && ws_bytes >= wbytes && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+                        const float* wsrc = p.Wt; float* wdst = (float*)ws;
+                        const int C = p.Ka, K = p.Cc;
+                        dim3 tg(cdiv(K, 32), cdiv(C, 32), ntaps);
+                        int rc = dispatch(stream, OpInfo{"transpose_filter", 0.0, 2.0 * wbytes}, [=](hipStream_t s) {
+                            transpose_filter_kernel<<<tg, 256, 0, s>>>(wsrc, wdst, C, K);
+                            return launched("transpose_filter_kernel");
+                        });
+                        if (rc != MV3D_OK) return rc;
+                        q.Wt = (const float*)ws; q.w_ks = 1; q.w_ns = p.Ka;
+                        use_t = true;
+                        used = (wbytes + 255) & ~(size_t)255;
+                    }
+                }
+                const bool km = use_t ? false : kmajor_in;
+                int ksplit = std::max(1, std::min(x.chunks, 512 / std::max(1, tiles * ny * zph)));
+                const size_t per_split = (size_t)p.N * p.Hc * p.Wc * p.Cc * sizeof(float);
+                while (ksplit > 1 && (!ws || used + (size_t)ksplit * per_split > ws_bytes)) --ksplit;
+                x.ksplit = ksplit;
+                q.ksplit = ksplit;
+                q.Part = ksplit > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + used) : nullptr;
+                dim3 grid(tiles, ny, zph * ksplit);
+                int rc = km ? launch_hconv<1, 1, 1, true, 4>(q, x, grid, lds, stream, "hconv<small-img,128px,N32,kmajorB>", who, flops, bytes)
+                            : launch_hconv<1, 1, 1, false, 4>(q, x, grid, lds, stream, "hconv<small-img,128px,N32,nmajorB>", who, flops, bytes);
+                if (rc != MV3D_OK) return rc;
+                if (ksplit > 1) { *epi_out = q; return 2; }
+                return MV3D_OK;
+            }
+        }
+    }
+    if (Hp * Wp < 64 || Wp < 8) return 1;
     // Configuration ladder, biggest tile first; step down while the launch would leave CUs idle.
     //   256 px (2 pixel groups per wave): halves per-tap operand traffic; needs a halo <= 78 KB so
     //   that two workgroups still share a CU.   64 px (2 waves): for layers with few pixels.
@@ -559,6 +632,25 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     dim3 grid(p.N * best.tiles_h * best.tiles_w, cdiv(p.Cc, 32 * NT), 1);
     IgemmParams q = p;
     q.ksplit = 1;
+    // Forward-direction filters ([tap][C][K], reduction index strided): make a [tap][K][C] copy in the
+    // workspace so that B fragments are 16-byte loads like in the backward-data direction.
+    bool use_t = false;
+    if (kmajor_in && p.Ka % 4 == 0 && !(disabled_paths() & 256)) {
+        const size_t wbytes = (size_t)ntaps * p.Ka * p.Cc * sizeof(float);
+        if (ws && ws_bytes >= wbytes && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+            const float* wsrc = p.Wt; float* wdst = (float*)ws;
+            const int C = p.Ka, K = p.Cc;
+            dim3 tg(cdiv(K, 32), cdiv(C, 32), ntaps);
+            int rc = dispatch(stream, OpInfo{"transpose_filter", 0.0, 2.0 * wbytes}, [=](hipStream_t s) {
+                transpose_filter_kernel<<<tg, 256, 0, s>>>(wsrc, wdst, C, K);
+                return launched("transpose_filter_kernel");
+            });
+            if (rc != MV3D_OK) return rc;
+            q.Wt = (const float*)ws; q.w_ks = 1; q.w_ns = p.Ka;      // [tap][Cc][Ka]
+            use_t = true;
+        }
+    }
+    const bool kmajor = use_t ? false : kmajor_in;
     if (nph == 1 && WAVES == 4 && (ntaps == 25 || ntaps == 9) && p.so_h == 1 && p.so_w == 1 && 2 * lds <= 160 * 1024 &&
         !(disabled_paths() & 128)) {
         // persistent kernel, one workgroup per CU (two halo buffers in LDS)
@@ -567,24 +659,6 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
         const int tiles_total = p.N * best.tiles_h * best.tiles_w;
         dim3 pgrid(std::min(tiles_total, std::max(1, 256 / ny)), ny, 1);
         const size_t lds2 = 2 * lds;
-        bool use_t = false;
-        if (kmajor && p.Ka % 4 == 0 && !(disabled_paths() & 256)) {
-            const size_t wbytes = (size_t)ntaps * p.Ka * p.Cc * sizeof(float);
-            if (ws && ws_bytes >= wbytes && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
-                // all taps are dense [Ka][Cc] blocks at widx * w_tap_stride
-                const float* wsrc = p.Wt; float* wdst = (float*)ws;
-                const int C = p.Ka, K = p.Cc;
-                dim3 tg(cdiv(K, 32), cdiv(C, 32), ntaps);
-                int rc = dispatch(stream, OpInfo{"transpose_filter", 0.0, 2.0 * wbytes}, [=](hipStream_t s) {
-                    transpose_filter_kernel<<<tg, 256, 0, s>>>(wsrc, wdst, C, K);
-                    return launched("transpose_filter_kernel");
-                });
-                if (rc != MV3D_OK) return rc;
-                q.Wt = (const float*)ws; q.w_ks = 1; q.w_ns = p.Ka;      // [tap][Cc][Ka]
-                use_t = true;
-            }
-        }
-        const bool kmajor = use_t ? false : ::mv3d::kmajor_of(p);
 #define MV3D_HCONVP(NTAPS_, MT_, NT_, KM_, PF_, W_, NAME) launch_hconvp<NTAPS_, MT_, NT_, KM_, PF_, W_>(q, best, pgrid, lds2, stream, NAME, who, flops, bytes)
         // 256-pixel tiles run as 8 waves x 32 pixels: two waves per SIMD cover each other's non-MFMA issue slots
         const int pf8 = cdiv(best.HR * best.HC * 8, 512);
