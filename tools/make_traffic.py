@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Build profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs).
+
+    python tools/make_traffic.py gpurun_out/pmc_fetch2 gpurun_out/pmc_write2 > profiles/traffic.json
+
+Per MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KB; on gfx950 FETCH_SIZE under-reports by 2x
+(64-byte requests counted as 32) and is doubled here; WRITE_SIZE is used as is. Values are means over the launches of a
+kernel instantiation within the profiled run, keyed by the bench label of that instantiation (only instantiations that
+serve exactly one label are listed; shared ones are keyed by their C++ name).
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+LABEL = {
+    'hconvp_kernel<25, 1, 1, false, 9, 8, 25, 25, 25>': 'hconvp<5x5,256px,N32,nmajorB>',
+    'hconvp_kernel<25, 1, 1, false, 13, 4, 25, 25, 25>': 'hconvp<5x5,128px,N32,nmajorB>',
+    'hconvp_kernel<25, 1, 2, false, 13, 4, 25, 25, 25>': 'hconvp<5x5,128px,N64,nmajorB>',
+    'hconv_kernel<4, 1, 1, false, 4>': 'hconv<4ph,128px,N32,nmajorB>',
+    'hconv_kernel<1, 1, 2, false, 4>': 'hconv<1ph,128px,N64,nmajorB>',
+    'wgrad_tile_kernel<7, 1>': 'wgrad_tile<5x5,K32>',
+    'wgrad_tile_kernel<7, 2>': 'wgrad_tile<5x5,K64>',
+    'wgrad_tile_kernel<5, 2>': 'wgrad_tile<3x3,K64>',
+    'fc_stream_kernel<false, 2>': 'fc_stream<fwd>',
+    'fc_stream_kernel<true, 2>': 'fc_stream<dgrad>',
+    'mv3d::fc_wgrad_kernel': 'fc_wgrad',
+    'mv3d::adam_kernel': 'adam',
+    'mv3d::reduce_slabs_kernel': 'reduce_slabs',
+    'mv3d::igemm_splitk_epilogue': 'igemm_splitk_epilogue',
+    'resample_kernel<false>': 'resample_fwd',
+    'resample_kernel<true>': 'resample_bwd',
+    'mv3d::pixel_loss_kernel': 'pixel_loss',
+    'thin_deconv_s2_kernel<5, 2>': 'thin_deconv_s2<2>',
+    'smallc_img2feat_kernel<1>': 'smallc_img2feat<N32>',
+}
+
+
+def means(d, counter):
+    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        if 'mv3d' not in k or r['Counter_Name'] != counter:
+            continue
+        k = k.replace('void mv3d::', '').split('(')[0]
+        acc.setdefault(k, []).append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch = means(sys.argv[1], 'FETCH_SIZE')
+write = means(sys.argv[2], 'WRITE_SIZE')
+out = collections.OrderedDict()
+for k in fetch:
+    fb = int(fetch[k] * 1024 * 2)
+    wb = int(write.get(k, 0.0) * 1024)
+    out[LABEL.get(k, k)] = {
+        'hbm_bytes_per_launch': fb + wb, 'fetch_bytes_x2_corrected': fb, 'write_bytes': wb, 'cxx_kernel': k,
+        'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB units, FETCH_SIZE doubled per '
+                  "MI355X_MICROARCH.md HBM section; mean over the kernel's launches"}
+json.dump(out, sys.stdout, indent=1)
+print()
