@@ -13,6 +13,7 @@ UNITS = {
     "core.hip": [],
     "conv.hip": [],
     "hconv.hip": [],
+    "bconv.hip": [],
     "wgrad_tile.hip": [],
     "fc.hip": [],
     "elem.hip": ["-ffp-contract=off"],

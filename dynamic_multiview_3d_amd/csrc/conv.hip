@@ -993,7 +993,8 @@ size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g) {
         if (b > igemm) igemm = b;
     }
     size_t fg = filtgrad_ws_bytes(g);
-    size_t filt = (size_t)g->kh * g->kw * g->C * g->K * sizeof(float);     // transposed filter copy for the forward kernel
+    // transposed / fragment-ordered split filter copy of the halo kernels (channel counts padded to the MFMA tile)
+    size_t filt = (size_t)g->kh * g->kw * ((g->C + 63) / 64 * 64) * ((g->K + 63) / 64 * 64) * sizeof(float);
     size_t m = igemm > fg ? igemm : fg;
     // small-image halo kernel: transposed filter copy + up to 16 chunk-split partial copies of an output
     const size_t big_out = out_img > out_feat ? out_img : out_feat;

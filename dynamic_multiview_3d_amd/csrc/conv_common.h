@@ -35,6 +35,21 @@ __device__ __forceinline__ float epilogue_value(const IgemmParams& p, float v, i
 }
 
 
+// Tile description shared by the halo-tile kernels (hconv.hip fp32, bconv.hip split-bf16).
+struct HconvExtra {
+    int TH, TW, tw_shift;
+    int tiles_h, tiles_w;
+    int HR, HC;
+    int dh_min, dw_min;
+    int chunks, ntaps_total;
+    int phase_split;     // 1: grid.z = stride phase; each workgroup computes ONE phase (more workgroups for small layers)
+    int G, img_shift;    // small images: a tile is G whole images of 2^img_shift phase-grid pixels (halos stacked vertically)
+    int HRi;             // halo rows per image (HR = G * HRi)
+    int ksplit;          // channel chunks are split over grid.z; raw partial sums go to p.Part, igemm_splitk_epilogue finishes
+    int dbg;             // MV3D_DBG diagnostics: 1 = no halo loads, 8 = skip the tap loop
+    int row_bytes;       // bconv (split-bf16) kernels: LDS bytes per halo row (padded for conflict-free 16-byte reads)
+};
+
 // hconv.hip: returns MV3D_OK after dispatching, or 1 if the problem is not eligible for the
 // halo-tile kernel (caller falls back to the generic igemm).
 // returns MV3D_OK after dispatching, 1 when not eligible, 2 when partial sums were written and the caller must
@@ -46,6 +61,15 @@ size_t fc_stream_ws_bytes(int B, int in, int out, bool trans);
 int try_fc_stream(bool trans, int B, int in, int out, const void* x, int x_ld, const void* W, void* y, int y_ld,
                   const mv3d_epilogue* epi, void* ws, size_t wsb, void* stream, const char* who,
                   void (*fill_epi)(IgemmParams&, const mv3d_epilogue*), void (*launch_epi)(const IgemmParams&, int, hipStream_t));
+// bconv.hip: split-bf16 (hi + lo, three bf16 MFMA products per fp32 product) halo-tile convolution.
+//   bconv_filter_bytes: workspace bytes of the fragment-ordered split filter for this problem
+//   launch_bconv: filter split + main kernel (2 launches); nph 1|4, MT/NT register blocking, 2 or 4 waves
+size_t bconv_filter_bytes(const IgemmParams& p, int NT);
+int bconv_lds_bytes(const HconvExtra& x);
+void bconv_set_rows(HconvExtra* x);
+int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid,
+                 void* wfrag, void* stream, const char* name, const char* who, double flops, double bytes);
+
 int try_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* dM, void* db, void* stream, const char* who);
 
 }  // namespace mv3d

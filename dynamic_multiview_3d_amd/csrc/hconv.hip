@@ -22,18 +22,6 @@ namespace mv3d {
 
 static inline bool kmajor_of(const IgemmParams& p) { return p.w_ns == 1; }
 
-struct HconvExtra {
-    int TH, TW, tw_shift;
-    int tiles_h, tiles_w;
-    int HR, HC;
-    int dh_min, dw_min;
-    int chunks, ntaps_total;
-    int phase_split;     // 1: grid.z = stride phase; each workgroup computes ONE phase (more workgroups for small layers)
-    int G, img_shift;    // small images: a tile is G whole images of 2^img_shift phase-grid pixels (halos stacked vertically)
-    int HRi;             // halo rows per image (HR = G * HRi)
-    int ksplit;          // channel chunks are split over grid.z; raw partial sums go to p.Part, igemm_splitk_epilogue finishes
-    int dbg;   // MV3D_DBG diagnostics: 1 = no halo loads, 8 = skip the tap loop
-};
 
 // One tap's operands in registers: A fragments (MT pixel groups x 16 k-steps) and B fragments
 // (16 k-steps x NT channel groups).  Two sets ping-pong so that the set for tap t+1 is being filled
@@ -480,14 +468,15 @@ static int launch_hconv(const IgemmParams& p, const HconvExtra& x, dim3 grid, si
 }
 
 // Tile search: TW in {8..64}, TH = PIX/TW; least padded MFMA work, halo size breaks ties.
-static bool pick_tile(const IgemmParams& p, int PIX, int Hp, int Wp, int dh_span, int dw_span, size_t lds_cap, HconvExtra* out) {
+static bool pick_tile(const IgemmParams& p, int PIX, int Hp, int Wp, int dh_span, int dw_span, size_t lds_cap, HconvExtra* out, bool b3 = false) {
     int64_t best_cost = -1;
     for (int sh = 3; sh <= 6; ++sh) {
         const int TW = 1 << sh, TH = PIX / TW;
         if (TH < 1 || TH > Hp * 2 || TW > Wp * 2) continue;
         const int th = cdiv(Hp, TH), tw = cdiv(Wp, TW);
         const int HR = (TH - 1) * p.sa_h + dh_span, HC = (TW - 1) * p.sa_w + dw_span;
-        const size_t lds = (size_t)HR * HC * 33 * sizeof(float);
+        size_t lds = (size_t)HR * HC * 33 * sizeof(float);
+        if (b3) { HconvExtra t = {}; t.HC = HC; t.HR = HR; t.TW = TW; bconv_set_rows(&t); lds = (size_t)bconv_lds_bytes(t); }
         if (lds > lds_cap) continue;
         const int64_t cost = (int64_t)th * tw * (PIX * 64 + HR * HC);
         if (best_cost < 0 || cost < best_cost) {
@@ -506,7 +495,8 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     if (p.fold || (nph != 1 && nph != 4)) return 1;
     if (p.Ka % 16 != 0 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15)) return 1;
     const bool kmajor_in = kmajor_of(p);
-    if (!kmajor_in && ((p.w_ns % 4) != 0 || (reinterpret_cast<uintptr_t>(p.Wt) & 15))) return 1;
+    const bool b3 = !(disabled_paths() & 4096);          // split-bf16 matrix-core path (bconv.hip); off = exact fp32 MFMA
+    if (!b3 && !kmajor_in && ((p.w_ns % 4) != 0 || (reinterpret_cast<uintptr_t>(p.Wt) & 15))) return 1;
     const int Hp = p.Hp[0], Wp = p.Wp[0];
     if (nph == 4 && (p.Hp[1] != Hp || p.Wp[1] != Wp)) return 1;
     if (Hp * Wp < 16 || Wp < 4) return 1;
@@ -541,6 +531,23 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
             const size_t lds = (size_t)x.HR * x.HC * 33 * sizeof(float);
             const int tiles = cdiv(p.N, x.G), ny = cdiv(p.Cc, 32);
             const int zph = (nph == 4) ? 4 : 1;
+            bconv_set_rows(&x);
+            const size_t wfb = bconv_filter_bytes(p, 1);
+            if (b3 && bconv_lds_bytes(x) <= 150 * 1024 && ws && ws_bytes >= wfb && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+                IgemmParams q = p;
+                const size_t used = (wfb + 255) & ~(size_t)255;
+                int ksplit = std::max(1, std::min(x.chunks, 512 / std::max(1, tiles * ny * zph)));
+                const size_t per_split = (size_t)p.N * p.Hc * p.Wc * p.Cc * sizeof(float);
+                while (ksplit > 1 && used + (size_t)ksplit * per_split > ws_bytes) --ksplit;
+                x.ksplit = ksplit;
+                q.ksplit = ksplit;
+                q.Part = ksplit > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + used) : nullptr;
+                dim3 grid(tiles, ny, zph * ksplit);
+                int rc = launch_bconv(q, x, 1, 1, 1, 4, grid, ws, stream, "bconv<small-img,128px,N32>", who, flops, bytes);
+                if (rc != MV3D_OK) return rc;
+                if (ksplit > 1) { *epi_out = q; return 2; }
+                return MV3D_OK;
+            }
             if (lds <= 150 * 1024) {
                 IgemmParams q = p;
                 // workspace: [transposed filter copy][split partials]
@@ -579,6 +586,60 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
         }
     }
     if (Hp * Wp < 64 || Wp < 8) return 1;
+    if (b3) {
+        // split-bf16 kernels: prefer 64 pixels x 32..64 columns per wave (operand reuse from registers); two
+        // workgroups share a CU, so ask for >= 512 workgroups before settling on a tile size
+        const int dh_span = dh_max - dh_min + 1, dw_span = dw_max - dw_min + 1;
+        const size_t wfb_max = bconv_filter_bytes(p, 2);
+        if (ws && ws_bytes >= wfb_max && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+            HconvExtra bx = {};
+            int MT = 0, NT = 1, WAVES = 4, fused = nph;
+            const char* name = nullptr;
+            if (nph == 1) {
+                struct Cand { int pix, MT, NT, WAVES; const char* name; };
+                const int n2 = p.Cc > 32 ? 2 : 1;
+                const Cand ladder[5] = {{256, 2, n2, 4, n2 == 2 ? "bconv<1ph,256px,N64>" : "bconv<1ph,256px,N32>"}, {256, 2, 1, 4, "bconv<1ph,256px,N32>"},
+                                        {128, 1, n2, 4, n2 == 2 ? "bconv<1ph,128px,N64>" : "bconv<1ph,128px,N32>"}, {128, 1, 1, 4, "bconv<1ph,128px,N32>"},
+                                        {64, 1, 1, 2, "bconv<1ph,64px,N32>"}};
+                for (int c = 0; c < 5; ++c) {
+                    const Cand& cd = ladder[c];
+                    if (cd.pix == 256 && Hp * Wp < 256) continue;
+                    HconvExtra x = {};
+                    if (!pick_tile(p, cd.pix, Hp, Wp, dh_span, dw_span, 78 * 1024, &x, true)) continue;
+                    const int64_t blocks = (int64_t)p.N * x.tiles_h * x.tiles_w * cdiv(p.Cc, 32 * cd.NT);
+                    bx = x; MT = cd.MT; NT = cd.NT; WAVES = cd.WAVES; name = cd.name;
+                    static int minblk = -1;
+                    if (minblk < 0) { const char* e = getenv("MV3D_BC_MINBLK"); minblk = e ? atoi(e) : 512; }
+                    if (blocks >= minblk) break;
+                }
+            } else {
+                HconvExtra x = {};
+                if (pick_tile(p, 128, Hp, Wp, dh_span, dw_span, 78 * 1024, &x, true)) {
+                    const int64_t fused_blocks = (int64_t)p.N * x.tiles_h * x.tiles_w * cdiv(p.Cc, 32);
+                    bx = x; MT = 1; NT = 1; WAVES = 4;
+                    if (fused_blocks >= 256) { fused = 4; name = "bconv<4ph,128px,N32>"; }
+                    else { fused = 1; bx.phase_split = 1; name = "bconv<phase-split,128px,N32>"; }
+                    if (fused == 1 && fused_blocks * 4 < 256) {
+                        HconvExtra x64 = {};
+                        if (pick_tile(p, 64, Hp, Wp, dh_span, dw_span, 78 * 1024, &x64, true)) {
+                            bx = x64; bx.phase_split = 1; WAVES = 2; name = "bconv<phase-split,64px,N32>";
+                        }
+                    }
+                }
+            }
+            if (MT != 0) {
+                bx.dh_min = dh_min; bx.dw_min = dw_min;
+                bx.chunks = cdiv(p.Ka, 32);
+                bx.ntaps_total = ntaps;
+                { const char* e = getenv("MV3D_DBG"); bx.dbg = e ? atoi(e) : 0; }
+                bconv_set_rows(&bx);
+                IgemmParams q = p;
+                q.ksplit = 1;
+                dim3 grid(p.N * bx.tiles_h * bx.tiles_w, cdiv(p.Cc, 32 * NT), bx.phase_split ? 4 : 1);
+                return launch_bconv(q, bx, fused, MT, NT, WAVES, grid, ws, stream, name, who, flops, bytes);
+            }
+        }
+    }
     // Configuration ladder, biggest tile first; step down while the launch would leave CUs idle.
     //   256 px (2 pixel groups per wave): halves per-tap operand traffic; needs a halo <= 78 KB so
     //   that two workgroups still share a CU.   64 px (2 waves): for layers with few pixels.

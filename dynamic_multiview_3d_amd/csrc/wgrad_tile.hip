@@ -30,6 +30,7 @@ struct WgTileParams {
     int IW, PH;          // 8 waves = IW item groups x PH pixel-pair ranges
     int ctiles;
     int ntiles_total, tiles_per_slab;
+    int b3;              // 1: split-bf16 kernel (wgrad_b3_kernel)
 };
 
 __device__ float4 g_zero16[4];        // 64 bytes of zeros in the code object: source of out-of-image LDS-DMA lanes
@@ -203,6 +204,250 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgTileParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 variant (see bconv.hip for the arithmetic): same work decomposition, but the reduction
+// (pixel) index is the MFMA k index of v_mfma_f32_32x32x16_bf16, 16 pixels per instruction.
+//   * staging goes through registers (LDS-DMA cannot convert): every thread prefetches its share of the
+//     next tile's fp32 halo + feature tile while the current tile is multiplied, then splits each value
+//     into hi/lo bf16 and writes four PLANES per buffer: image hi, image lo ([halo pixel][32 ch], 64-byte
+//     rows) and feature hi, lo ([pixel][32 k] per k-tile);
+//   * both MFMA operands need "8 consecutive pixels of one channel" per lane while LDS holds
+//     [pixel][channel]: ds_read_b64_tr_b16 (gfx950 transposing read) delivers exactly that -- 4 pixels x 16
+//     channels per 16-lane group, two reads per operand; four consecutive pixels are 256 contiguous bytes,
+//     i.e. conflict-free.  Stride-2 layers store even and odd halo columns apart so that this still holds;
+//   * a wave's items all share one k-tile, so the feature operand is read once per 16-pixel step and each
+//     tap adds 4 reads + 3 MFMAs.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wsplit4(const float4& v, uint2& hi, uint2& lo) {
+    wbf16x4 h, l;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+__device__ __forceinline__ uint2 tr_read(const unsigned char* lds_ptr) {
+    ws16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)lds_ptr);
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <int TPW, int NKT, int NI>
+__global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
+    constexpr int NF = 4;                               // feature float4 slots per thread (TPIX * NKT * 8 / 512 <= 4)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int iw = wave % p.IW;                         // (k-tile, tap group)
+    const int ph = wave / p.IW;                         // pixel-step range
+    const int tg_per_kt = p.IW / NKT;
+    const int kt_w = iw / tg_per_kt, tg = iw - kt_w * tg_per_kt;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ct = blockIdx.x % p.ctiles, kg = blockIdx.x / p.ctiles;
+    const int c0 = ct * 32, k0 = kg * 32 * NKT;
+    const int slab = blockIdx.y;
+    const int tile_begin = slab * p.tiles_per_slab;
+    const int tile_end = min(tile_begin + p.tiles_per_slab, p.ntiles_total);
+
+    const int halo_pix = p.HR * p.HC;
+    const int img_plane = halo_pix * 64;                // bytes of one image plane
+    const int feat_plane = p.TPIX * 64;
+    const int buf_bytes = 2 * img_plane + 2 * NKT * feat_plane;
+    const int HCh = (p.HC + 1) >> 1;                    // stride-2: even halo columns first, then the odd ones
+
+    // this wave's taps (same k-tile): surplus slots recompute the last real tap into an accumulator never stored
+    int tapoff[TPW], item_tap[TPW];
+    bool item_ok[TPW];
+    const int tap_lo = (p.ntaps * tg) / tg_per_kt, tap_n = (p.ntaps * (tg + 1)) / tg_per_kt - tap_lo;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        int tap = tap_lo + i;
+        item_ok[i] = i < tap_n;
+        if (tap >= p.ntaps) tap = p.ntaps - 1;
+        item_tap[i] = tap;
+        const int dh = tap / p.kw, dw = tap - dh * p.kw;
+        const int cs = (p.sw == 2) ? (dw & 1) * HCh + (dw >> 1) : dw;
+        tapoff[i] = (dh * p.HC + cs) * 64;
+    }
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // lane roles of the transposing read: address supplier (row q, column quad pp of 16-channel group g)
+    const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    const int col_bytes = (16 * g16 + 4 * pp) * 2;
+
+    // ---- staging: global -> registers (prefetch) -> split -> LDS planes -------------------------
+    float4 vi[NI], vf[NF];
+    float4 bsum[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_bias = p.bias_out != nullptr && ct == 0;
+    const int n_img4 = halo_pix * 8, n_feat4 = p.TPIX * NKT * 8;
+    auto fetch = [&](int tile) {
+        int b = tile;
+        const int tw_i = b % p.tiles_w; b /= p.tiles_w;
+        const int th_i = b % p.tiles_h;
+        const int n = b / p.tiles_h;
+        const int oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
+        const int ih0 = oh0 * p.sh - p.pt, iw0 = ow0 * p.sw - p.pl;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = j * 512 + tid;
+            const int pix = idx >> 3, c4 = idx & 7;
+            const int hr = pix / p.HC, hc = pix - hr * p.HC;
+            const int ih = ih0 + hr, iwc = iw0 + hc, ch = c0 + c4 * 4;
+            const bool ok = idx < n_img4 && (unsigned)ih < (unsigned)p.H && (unsigned)iwc < (unsigned)p.W && ch < p.C;
+            const float* src = ok ? p.img + (int64_t)((n * p.H + ih) * p.W + iwc) * p.img_ld + ch : p.img;
+            const float4 t4 = *reinterpret_cast<const float4*>(src);
+            vi[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int idx = j * 512 + tid;
+            const int kt = idx / (p.TPIX * 8), rem = idx - kt * (p.TPIX * 8);
+            const int pq = rem >> 3, c4 = rem & 7;
+            const int oh = oh0 + (pq >> p.tw_shift), ow = ow0 + (pq & (p.TW - 1)), kk = k0 + kt * 32 + c4 * 4;
+            const bool ok = idx < n_feat4 && oh < p.Ho && ow < p.Wo && kk < p.K;
+            const float* src = ok ? p.feat + (int64_t)((n * p.Ho + oh) * p.Wo + ow) * p.feat_ld + kk : p.feat;
+            const float4 t4 = *reinterpret_cast<const float4*>(src);
+            vf[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](unsigned char* buf) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = j * 512 + tid;
+            if (idx < n_img4) {
+                const int pix = idx >> 3, c4 = idx & 7;
+                const int hr = pix / p.HC, hc = pix - hr * p.HC;
+                const int cs = (p.sw == 2) ? (hc & 1) * HCh + (hc >> 1) : hc;
+                unsigned char* d = buf + (hr * p.HC + cs) * 64 + c4 * 8;
+                uint2 hi, lo;
+                wsplit4(vi[j], hi, lo);
+                *reinterpret_cast<uint2*>(d) = hi;
+                *reinterpret_cast<uint2*>(d + img_plane) = lo;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int idx = j * 512 + tid;
+            if (idx < n_feat4) {
+                const int kt = idx / (p.TPIX * 8), rem = idx - kt * (p.TPIX * 8);
+                unsigned char* d = buf + 2 * img_plane + kt * 2 * feat_plane + (rem >> 3) * 64 + (rem & 7) * 8;
+                uint2 hi, lo;
+                wsplit4(vf[j], hi, lo);
+                *reinterpret_cast<uint2*>(d) = hi;
+                *reinterpret_cast<uint2*>(d + feat_plane) = lo;
+                bsum[j].x += vf[j].x; bsum[j].y += vf[j].y; bsum[j].z += vf[j].z; bsum[j].w += vf[j].w;
+            }
+        }
+    };
+
+    const int steps_total = p.TPIX >> 4;
+    const int nsteps = steps_total / p.PH;
+    const int s_begin = ph * nsteps;
+
+    if (tile_begin < tile_end) { fetch(tile_begin); commit(smb); }
+    int cur = 0;
+    for (int tile = tile_begin; tile < tile_end; ++tile, cur ^= 1) {
+        __syncthreads();                                        // buffer `cur` complete; the other one no longer read
+        const unsigned char* buf = smb + cur * buf_bytes;
+        const bool has_next = tile + 1 < tile_end;
+        if (has_next) fetch(tile + 1);                          // in flight under this tile's MFMAs
+
+        const unsigned char* fb = buf + 2 * img_plane + kt_w * 2 * feat_plane + col_bytes;
+        for (int s = s_begin; s < s_begin + nsteps; ++s) {
+            // pixels of this step handled by this lane as address supplier: 16 s + 8 lh + 4 r + q, r = 0, 1
+            const int px0 = 16 * s + 8 * lh + q, px1 = px0 + 4;
+            const int a0 = (((px0 >> p.tw_shift) * p.sh) * p.HC + (px0 & (p.TW - 1))) * 64 + col_bytes;
+            const int a1 = (((px1 >> p.tw_shift) * p.sh) * p.HC + (px1 & (p.TW - 1))) * 64 + col_bytes;
+            const uint2 bh0 = tr_read(fb + px0 * 64), bh1 = tr_read(fb + px1 * 64);
+            const uint2 bl0 = tr_read(fb + feat_plane + px0 * 64), bl1 = tr_read(fb + feat_plane + px1 * 64);
+            const wbf16x8 bh = __builtin_bit_cast(wbf16x8, make_uint4(bh0.x, bh0.y, bh1.x, bh1.y));
+            const wbf16x8 bl = __builtin_bit_cast(wbf16x8, make_uint4(bl0.x, bl0.y, bl1.x, bl1.y));
+            uint2 ar[2][4];
+            auto lda = [&](int i, uint2 (&a)[4]) {
+                const unsigned char* pa = buf + tapoff[i];
+                a[0] = tr_read(pa + a0); a[1] = tr_read(pa + a1);
+                a[2] = tr_read(pa + img_plane + a0); a[3] = tr_read(pa + img_plane + a1);
+            };
+            lda(0, ar[0]);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                if (i + 1 < TPW) lda(i + 1, ar[(i + 1) & 1]);
+                const uint2 (&a)[4] = ar[i & 1];
+                const wbf16x8 ah = __builtin_bit_cast(wbf16x8, make_uint4(a[0].x, a[0].y, a[1].x, a[1].y));
+                const wbf16x8 al = __builtin_bit_cast(wbf16x8, make_uint4(a[2].x, a[2].y, a[3].x, a[3].y));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+            }
+        }
+        if (has_next) commit(smb + (cur ^ 1) * buf_bytes);
+    }
+
+    // combine the PH pixel-range partials of each item group through LDS (fixed order), then store
+    __syncthreads();
+    float* smem = reinterpret_cast<float*>(smb);
+    for (int r = 1; r < p.PH; ++r) {
+        float* xch = smem + (iw * TPW) * 1024 + lane;            // [item][16 regs][64 lanes]
+        if (ph == r) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) xch[(i * 16 + e) * 64] = acc[i][e];
+        }
+        __syncthreads();
+        if (ph == 0) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] += xch[(i * 16 + e) * 64];
+        }
+        __syncthreads();
+    }
+    if (ph == 0) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (!item_ok[i]) continue;
+            float* out = p.out + ((int64_t)slab * p.ntaps + item_tap[i]) * p.C * p.K;
+            const int k = k0 + kt_w * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (c < p.C && k < p.K) out[(int64_t)c * p.K + k] = acc[i][r];
+            }
+        }
+    }
+    if (do_bias) {
+        // bias gradient = column sums of the feature tiles: per-thread fp32 partials (fixed k columns per
+        // thread), combined through LDS in a fixed order
+        __syncthreads();
+        float4* bx = reinterpret_cast<float4*>(smb);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) bx[j * 512 + tid] = bsum[j];
+        __syncthreads();
+        if (tid < 32 * NKT) {
+            const int kt = tid >> 5, kk = tid & 31;
+            // staging slot idx = j*512 + thread = kt*TPIX*8 + pixel*8 + (k>>2) holds that thread's sum over all tiles
+            const float* bf = reinterpret_cast<const float*>(smb);
+            float t = 0.f;
+            for (int pq = 0; pq < p.TPIX; ++pq) t += bf[((kt * p.TPIX + pq) * 8 + (kk >> 2)) * 4 + (kk & 3)];
+            const int k = k0 + kt * 32 + kk;
+            if (k < p.K) p.bias_out[(int64_t)slab * p.K + k] = t;
+        }
+    }
+}
+
 template <int TPW, int NKT>
 static int launch_wgt(const WgTileParams& p, dim3 grid, size_t lds, void* stream, const char* name, const char* who,
                       double flops, double bytes) {
@@ -214,6 +459,21 @@ static int launch_wgt(const WgTileParams& p, dim3 grid, size_t lds, void* stream
     }
     return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
         wgrad_tile_kernel<TPW, NKT><<<grid, 512, lds, s>>>(p);
+        return launched(who);
+    });
+}
+
+template <int TPW, int NKT, int NI>
+static int launch_wgb(const WgTileParams& p, dim3 grid, size_t lds, void* stream, const char* name, const char* who,
+                      double flops, double bytes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_b3_kernel<TPW, NKT, NI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
+        wgrad_b3_kernel<TPW, NKT, NI><<<grid, 512, lds, s>>>(p);
         return launched(who);
     });
 }
@@ -233,7 +493,9 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
         if (g->K > 32) { NKT = 2; IW = 4; PH = 2; TPW = 5; cfg = 3; }       // 18 items: 5,5,4,4
         else { NKT = 1; IW = 2; PH = 4; TPW = 5; cfg = 2; }                 // 9 items: 5,4
     } else return false;
+    const bool b3 = !(disabled_paths() & 4096);          // split-bf16 kernel: waves = (k-tile, tap group) x pixel range
     WgTileParams p = {};
+    p.b3 = b3 ? 1 : 0;
     int ho, wo;
     same_pad(g->H, g->kh, g->sh, &ho, &p.pt);
     same_pad(g->W, g->kw, g->sw, &wo, &p.pl);
@@ -241,7 +503,7 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     int64_t best = -1;
     const size_t xchg = (PH > 1) ? (size_t)IW * TPW * 4096 : 0;            // end-of-kernel partial exchange
     for (int tpix = 128; tpix >= 64 && best < 0; tpix >>= 1) {
-        if ((tpix >> 1) / PH < 2) break;
+        if (b3 ? ((tpix >> 4) % PH != 0) : ((tpix >> 1) / PH < 2)) break;
         for (int sh = 3; sh <= 6; ++sh) {
             const int TW = 1 << sh, TH = tpix / TW;
             if (TH < 1 || TH > g->Ho * 2 || TW > g->Wo * 2) continue;
@@ -249,6 +511,7 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
             const int HR = (TH - 1) * g->sh + g->kh, HC = (TW - 1) * g->sw + g->kw;
             const size_t lds = std::max(2 * (size_t)(((HR * HC + tpix * NKT + 7) / 8) * 1024), xchg);
             if (lds > 160 * 1024) continue;
+            if (b3 && HR * HC * 8 > 8 * 512) continue;                      // staging registers: <= 8 float4 per thread
             const int64_t cost = (int64_t)th * tw * (tpix * 64 + HR * HC);
             if (best < 0 || cost < best) {
                 best = cost;
@@ -275,6 +538,7 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     *nslab_out = nslab;
     *cfg_out = cfg;
     *lds_out = std::max(2 * (size_t)(((p.HR * p.HC + p.TPIX * NKT + 7) / 8) * 1024), xchg);
+    if (b3) *lds_out = std::max(*lds_out, (size_t)32 * 1024);              // bias partial exchange
     return true;
 }
 
@@ -283,6 +547,15 @@ int wgrad_tile_launch(const mv3d_conv_geom* g, WgTileParams p, int nslab, int cf
     const double bytes = 4.0 * ((double)g->N * g->H * g->W * g->C + (double)g->N * g->Ho * g->Wo * g->K + (double)g->kh * g->kw * g->C * g->K);
     const int NKTv = (cfg & 1) ? 2 : 1;
     dim3 grid(p.ctiles * cdiv(g->K, 32 * NKTv), nslab);
+    if (p.b3) {
+        const bool ni4 = p.HR * p.HC * 8 <= 4 * 512;
+        switch (cfg) {
+            case 0: return ni4 ? launch_wgb<7, 1, 4>(p, grid, lds, stream, "wgrad_b3<5x5,K32>", who, flops, bytes) : launch_wgb<7, 1, 8>(p, grid, lds, stream, "wgrad_b3<5x5,K32>", who, flops, bytes);
+            case 1: return ni4 ? launch_wgb<7, 2, 4>(p, grid, lds, stream, "wgrad_b3<5x5,K64>", who, flops, bytes) : launch_wgb<7, 2, 8>(p, grid, lds, stream, "wgrad_b3<5x5,K64>", who, flops, bytes);
+            case 2: return ni4 ? launch_wgb<5, 1, 4>(p, grid, lds, stream, "wgrad_b3<3x3,K32>", who, flops, bytes) : launch_wgb<5, 1, 8>(p, grid, lds, stream, "wgrad_b3<3x3,K32>", who, flops, bytes);
+            default: return ni4 ? launch_wgb<5, 2, 4>(p, grid, lds, stream, "wgrad_b3<3x3,K64>", who, flops, bytes) : launch_wgb<5, 2, 8>(p, grid, lds, stream, "wgrad_b3<3x3,K64>", who, flops, bytes);
+        }
+    }
     switch (cfg) {
         case 0: return launch_wgt<7, 1>(p, grid, lds, stream, "wgrad_tile<5x5,K32>", who, flops, bytes);
         case 1: return launch_wgt<7, 2>(p, grid, lds, stream, "wgrad_tile<5x5,K64>", who, flops, bytes);

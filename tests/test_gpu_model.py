@@ -34,8 +34,9 @@ def _activation_pattern_override(model, tape):
     from dynamic_multiview_3d_amd.graph import ConvNode, LinearNode
     acts = [n for n in model.graph.nodes if isinstance(n, (ConvNode, LinearNode)) and n.act in (1, 2)]
     assert len(acts) == len(tape.act_inputs)
-    override, flips = [], 0
+    override, flips, total = [], 0, 0
     for n, pre in zip(acts, tape.act_inputs):
+        total += pre.size
         out = n.y.value().detach().cpu().numpy().reshape(pre.shape)
         if n.act == 2:      # relu keeps -0.0 for negative inputs
             dev_sign = np.where(out > 0, 1.0, np.where(np.signbit(out), -1.0, 0.0))
@@ -48,6 +49,9 @@ def _activation_pattern_override(model, tape):
             override.append(np.where(diff, dev_sign, np.sign(pre)))
         else:
             override.append(None)
+    # how many elements may sit that close to zero: summation-order / split-bf16 noise is a few 1e-6 of the
+    # layer maximum, the density of pre-activations at 0 is ~0.4/sigma, max ~ 5 sigma => ~1e-5 of the elements
+    assert flips <= 8 + 2e-5 * total, (flips, total)
     return override, flips
 
 
@@ -67,7 +71,6 @@ def _check_model(cls, variant, dead=()):
     g.run_backward()
     torch.cuda.synchronize()
     override, flips = _activation_pattern_override(model, tape)
-    assert flips <= 8, flips
     if flips:
         out, grads, tape = omodels.run(builder, {k: v.copy() for k, v in variables.items()}, feeds, sign_override=override)
     assert _rel(model.flow_field.numpy(), out['flow_field']) < 1e-4
@@ -136,7 +139,6 @@ def _check_generic(model, builder, feeds, out_names):
     g.run_backward()
     torch.cuda.synchronize()
     override, flips = _activation_pattern_override(model, tape)
-    assert flips <= 8, flips
     if flips:
         out, grads, tape = omodels.run(builder, {k: v.copy() for k, v in variables.items()}, feeds, sign_override=override)
     for attr, key in out_names.items():
