@@ -30,7 +30,13 @@ import numpy as np
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def is_split_bf16(label):
+    """Kernels that evaluate every fp32 product as three bf16 MFMA products (bconv.hip)."""
+    return label.startswith('bconv') or '_b3' in label
 TRAIN_MFLOP_PER_IMAGE_CONV = 3035.6   # BASELINE.md section 2 (fwd + dgrad + wgrad, no dgrad for e0)
 TRAIN_MFLOP_PER_IMAGE_ALL = 3440.0
 
@@ -211,10 +217,14 @@ def main():
         "metric": "train images/sec, appearance-flow encoder-decoder 128x128x3 (fwd+bwd+Adam)",
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if (os.environ.get('MV3D_DISABLE') and int(os.environ['MV3D_DISABLE']) & 4096) else "bf16x3",
+        "data": "synthetic",
         "config": {"workload": "appflow_offset: AppearanceFlowModel 128x128x3, batch %d per GPU, Adam lr 1e-4, "
                                "random-init weights (reference initialisers)" % args.batch,
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                   "precision": "conv / deconv / fc GEMMs: fp32 operands split into bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 products per "
+                                "fp32 product, fp32 accumulation (error ~1e-6 of the tensor scale; MV3D_DISABLE=4096 selects the exact "
+                                "fp32-MFMA kernels); activations, loss, resampler, Adam and all stored tensors fp32",
                    "launches_per_step": g.n_launch_fwd + g.n_launch_bwd + 1},
         "loss": round(loss, 6),
     }
@@ -222,8 +232,14 @@ def main():
         dom_name, dom = dominant, kern[dominant]
         if dom['flops'] > 0:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
+            if is_split_bf16(dom_name):
+                # algorithmic FLOPs against the dense bf16 peak; the kernel executes 3 MFMA FLOPs per algorithmic one
+                roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "mfma_dtype": "bf16 (split: 3 products per f32 product)",
+                        "executed_tflops": round(3 * ach, 2), "frac_executed": round(3 * ach / PEAK_BF16_MFMA_TFLOPS, 4)}
+            else:
+                roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "mfma_dtype": "f32"}
         else:
             ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -245,11 +261,16 @@ def main():
         mfma = {n: k for n, k in table.items() if k['flops'] > 0}
         conv_ms = sum(k['ms'] for k in mfma.values())
         conv_fl = sum(k['flops'] for k in mfma.values())
+        hbm = {n: k for n, k in table.items() if k['flops'] <= 0 and k['bytes'] > 0}
+        hbm_ms = sum(k['ms'] for k in hbm.values())
         out["stack"] = {"source": "HIP events around every launch during the warm-up steps",
                         "gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
                         "mfma_kernels_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                         "mfma_kernels_frac_of_f32_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                        "mfma_kernels_share_of_gpu_time": round(conv_ms / gpu_ms, 4)}
+                        "mfma_kernels_frac_of_bf16_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "mfma_kernels_share_of_gpu_time": round(conv_ms / gpu_ms, 4),
+                        "hbm_kernels_gbs": round(sum(k['bytes'] for k in hbm.values()) / (hbm_ms * 1e-3) / 1e9, 1) if hbm_ms > 0 else None,
+                        "hbm_kernels_share_of_gpu_time": round(hbm_ms / gpu_ms, 4)}
         if args.dump_kernels and rank == 0:
             for n, k in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
                 rate = ("%7.1f TF/s" % (k['flops'] / k['ms'] / 1e9)) if k['flops'] > 0 else ("%7.0f GB/s" % (k['bytes'] / k['ms'] / 1e6))

@@ -636,6 +636,10 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
                 IgemmParams q = p;
                 q.ksplit = 1;
                 dim3 grid(p.N * bx.tiles_h * bx.tiles_w, cdiv(p.Cc, 32 * NT), bx.phase_split ? 4 : 1);
+                if (getenv("MV3D_TRACE"))
+                    fprintf(stderr, "[mv3d] %-22s %-30s N=%d in %dx%dx%d (stride %d) out %dx%dx%d taps=%d tile %dx%d halo %dx%d lds=%d grid=%dx%dx%d %.2f GFLOP\n",
+                            who, name, p.N, p.Ha, p.Wa, p.Ka, p.sa_h, p.Hc, p.Wc, p.Cc, ntaps, bx.TH, bx.TW, bx.HR, bx.HC,
+                            bconv_lds_bytes(bx), grid.x, grid.y, grid.z, flops * 1e-9);
                 return launch_bconv(q, bx, fused, MT, NT, WAVES, grid, ws, stream, name, who, flops, bytes);
             }
         }

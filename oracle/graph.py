@@ -30,12 +30,18 @@ class Tape:
     'fc1/Matrix', 'pre_image0/e0/b', ...) to arrays; missing ones are created with the
     reference initialisers from `rng` (tf_utils.py:58-65, 74-80, 91-95)."""
 
-    def __init__(self, variables=None, rng=None, dtype=np.float32, sign_override=None):
+    def __init__(self, variables=None, rng=None, dtype=np.float32, sign_override=None, warp_override=None):
         # sign_override: optional list (one entry per activation call, in call order) of sign arrays to
         # use in the activation's backward instead of sign(x).  lrelu'/relu' are discontinuous at 0,
         # so a pre-activation within rounding noise of 0 may legitimately get either slope depending
         # on summation order; parity tests pass the device's pattern for exactly those elements.
         self.sign_override = sign_override
+        # warp_override: optional list (one entry per resample_layer call) of sampling coordinates to use instead
+        # of the computed ones.  The sampler's gradient w.r.t. the coordinates jumps where a coordinate crosses
+        # an integer (floor picks another cell); parity tests substitute the device's coordinates for exactly
+        # the samples whose cell differs, after checking that the coordinates themselves agree to rounding.
+        self.warp_override = warp_override
+        self.warp_inputs = []     # sampling coordinates, in resample_layer call order
         self.act_inputs = []      # pre-activation arrays, in activation call order
         self.vars = OrderedDict() if variables is None else variables
         self.rng = rng
@@ -160,10 +166,15 @@ class Tape:
 
     def resample_layer(self, src, warp, name='tgt_img'):
         """tf_utils.py:40-42."""
-        y = Node(ops.resampler_fwd(src.v, warp.v))
+        idx = len(self.warp_inputs)
+        self.warp_inputs.append(warp.v)
+        wv = warp.v
+        if self.warp_override is not None and self.warp_override[idx] is not None:
+            wv = self.warp_override[idx].astype(warp.v.dtype)
+        y = Node(ops.resampler_fwd(src.v, wv))
 
         def back():
-            dd, dw = ops.resampler_bwd(src.v, warp.v, y.g, need_ddata=src.needs_grad)
+            dd, dw = ops.resampler_bwd(src.v, wv, y.g, need_ddata=src.needs_grad)
             if src.needs_grad:
                 src.acc(dd)
             warp.acc(dw)

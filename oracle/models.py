@@ -302,9 +302,9 @@ class AdamState:
         self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
 
 
-def run(builder, variables, feeds, dtype=np.float32, rng=None, backward=True, sign_override=None, **kw):
+def run(builder, variables, feeds, dtype=np.float32, rng=None, backward=True, sign_override=None, warp_override=None, **kw):
     """Evaluate one graph: returns (outputs {name: array}, grads {var: array}, tape)."""
-    t = Tape(variables, rng=rng, dtype=dtype, sign_override=sign_override)
+    t = Tape(variables, rng=rng, dtype=dtype, sign_override=sign_override, warp_override=warp_override)
     nodes = {k: t.const(v) for k, v in feeds.items()}
     out = builder(t, nodes, **kw)
     grads = t.backward(out['loss']) if (backward and 'loss' in out) else {}
