@@ -53,6 +53,10 @@ STATUS_FUNCS = {
     "mv3d_pixel_loss": [_i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "mv3d_fill": [_vp, _i64, _f, _vp],
     "mv3d_adam_step": [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _f, _vp],
+    "mv3d_filter_cache_bind": [_G, _i, _vp, _vp, _sz],
+    "mv3d_filter_cache_commit": [_vp, _sz, _vp],
+    "mv3d_filter_cache_refresh": [_vp],
+    "mv3d_filter_cache_clear": [],
     "mv3d_plan_begin": [_vp],
     "mv3d_plan_end": [],
     "mv3d_plan_run": [_vp, _vp],
@@ -69,6 +73,8 @@ OTHER_FUNCS = {
     "mv3d_last_error": (C.c_char_p, []),
     "mv3d_conv_workspace_bytes": (_sz, [_G]),
     "mv3d_fc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mv3d_filter_prepared_bytes": (_sz, [_G, _i]),
+    "mv3d_filter_cache_table_bytes": (_sz, []),
     "mv3d_plan_create": (_vp, []),
     "mv3d_plan_destroy": (None, [_vp]),
     "mv3d_plan_size": (_i, [_vp]),

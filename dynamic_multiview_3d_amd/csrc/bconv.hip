@@ -20,6 +20,8 @@
 //     loop unrolled by two so no register copies), stride-2 transposed convs as 4 phases from one halo.
 #include "conv_common.h"
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace mv3d {
 
@@ -35,6 +37,89 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
     l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
     hi = __builtin_bit_cast(uint2, h);
     lo = __builtin_bit_cast(uint2, l);
+}
+
+
+// Halo staging shared by the bconv kernels: fp32 global -> split -> LDS.  A thread owns one 4-channel group
+// (c4 = tid & 7) and every (NTHR/8)-th halo pixel; the (row, column) of its pixels advance by a constant step, so
+// the loop carries no divisions and only a handful of integer instructions per 16-byte piece (the address
+// arithmetic of a naive index -> (row, column) decomposition costs more than the MFMAs of a small layer).
+template <int NTHR>
+__device__ __forceinline__ void bconv_stage_halo(const IgemmParams& p, const HconvExtra& x, unsigned char* halo, int cc, int n,
+                                                 int ih0, int iw0, int tid) {
+    constexpr int PS = NTHR / 8;                         // pixel step between a thread's pieces
+    const int c4 = tid & 7;
+    const int halo_pix = x.HR * x.HC;
+    const int ch = cc * 32 + c4 * 4;
+    const bool ch_ok = ch < p.Ka && !(x.dbg & 1);
+    const int dq = PS / x.HC, dr = PS - dq * x.HC;       // wave-uniform (scalar) division, once per call
+    int pix = tid >> 3;
+    int hrv = (int)(((unsigned)pix * (unsigned)x.inv_hc) >> 20), hc = pix - hrv * x.HC;
+    for (; pix < halo_pix;) {
+        float4 v[8];
+        int lofs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int g = x.G > 1 ? (int)(((unsigned)hrv * (unsigned)x.inv_hri) >> 20) : 0;
+            const int hr = hrv - g * x.HRi;
+            const int ih = ih0 + hr, iw = iw0 + hc;
+            const bool ok = ch_ok && pix < halo_pix && n + g < p.N && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+            const float* src = ok ? p.A + (int64_t)(((n + g) * p.Ha + ih) * p.Wa + iw) * p.a_ld + ch : p.A;
+            const float4 t4 = *reinterpret_cast<const float4*>(src);
+            v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+            lofs[u] = pix < halo_pix ? hrv * x.row_bytes + hc * BC_PIXB + c4 * 8 : -1;
+            pix += PS; hc += dr; hrv += dq;
+            if (hc >= x.HC) { hc -= x.HC; ++hrv; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (lofs[u] >= 0) {
+                uint2 hi, lo;
+                split4(v[u], hi, lo);
+                *reinterpret_cast<uint2*>(halo + lofs[u]) = hi;
+                *reinterpret_cast<uint2*>(halo + lofs[u] + 64) = lo;
+            }
+        }
+    }
+}
+
+// Output tile store shared by the bconv kernels.  acc rows: q = 8*(r>>2) + (r&3) + 4*lh inside a 32-pixel group; four
+// consecutive r are four consecutive pixels of one tile row, so one address is computed per group of four.  Tiles
+// that lie completely inside the output take a path without per-element bounds checks.
+template <int MT, int NT>
+__device__ __forceinline__ void bconv_store_tile(const IgemmParams& p, const HconvExtra& x, const f32x16 (&acc)[MT][NT], int wave, int lane,
+                                                 int n, int oh0, int ow0, int n0, int phh, int phw, int zks) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int Hp = p.Hp[0], Wp = p.Wp[0];
+    const int64_t npix_total = (int64_t)p.N * p.Hc * p.Wc;
+    const bool interior = n + x.G <= p.N && oh0 + x.TH <= Hp && ow0 + x.TW <= Wp && n0 + 32 * NT <= p.Cc && !(x.dbg & 16);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+            const int col = n0 + y * 32 + li;
+            const float bias = (p.bias && col < p.Cc) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int q = (wave * MT + m) * 32 + 8 * grp + 4 * lh;
+                const int g = q >> x.img_shift, qr = q & ((1 << x.img_shift) - 1);
+                const int ohp = oh0 + (qr >> x.tw_shift), owp = ow0 + (qr & (x.TW - 1));
+                const int64_t pix0 = (int64_t)((n + g) * p.Hc + ohp * p.so_h + phh) * p.Wc + owp * p.so_w + phw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[m][y][4 * grp + j];
+                    const int64_t pix = pix0 + j * p.so_w;
+                    if (interior || (n + g < p.N && ohp < Hp && owp + j < Wp && col < p.Cc && !(x.dbg & 16))) {
+                        if (x.ksplit > 1) p.Part[((int64_t)zks * npix_total + pix) * p.Cc + col] = a;
+                        else {
+                            float v = act_apply(a + bias, p.act, p.leak);
+                            if (p.gact != MV3D_ACT_NONE) v *= act_grad_from_out(p.gref[pix * p.g_ld + col], p.gact, p.gleak);
+                            p.Out[pix * p.c_ld + col] = v;
+                        }
+                    }
+                }
+            }
+        }
 }
 
 // Filter -> fragment order.  Wf[((t * chunks + cc) * ntiles + nt) * 4 + (s * 2 + part)][lane] (16 bytes each):
@@ -155,35 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void bconv_kernel(const IgemmParams p, 
         if (cc > cc_begin) __syncthreads();
         // halo staging: batches of 8 independent 16-byte loads per thread, then split + LDS stores;
         // out-of-image pixels load a valid dummy address and are zeroed
-        for (int base = 0; base < halo_pix * 8; base += NTHR * 8) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * NTHR + tid;
-                const int pix = idx >> 3, c4 = idx & 7;
-                const int hrv = pix / x.HC, hc = pix - hrv * x.HC;
-                const int g = hrv / x.HRi, hr = hrv - g * x.HRi;
-                const int ih = ih0 + hr, iw = iw0 + hc;
-                const int ch = cc * 32 + c4 * 4;
-                const bool ok = !(x.dbg & 1) && idx < halo_pix * 8 && n + g < p.N && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa && ch < p.Ka;
-                const float* src = ok ? p.A + (int64_t)(((n + g) * p.Ha + ih) * p.Wa + iw) * p.a_ld + ch : p.A;
-                const float4 t4 = *reinterpret_cast<const float4*>(src);
-                v[u] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * NTHR + tid;
-                if (idx < halo_pix * 8) {
-                    const int pix = idx >> 3, c4 = idx & 7;
-                    const int hrv = pix / x.HC, hc = pix - hrv * x.HC;
-                    unsigned char* d = halo + hrv * x.row_bytes + hc * BC_PIXB + c4 * 8;
-                    uint2 hi, lo;
-                    split4(v[u], hi, lo);
-                    *reinterpret_cast<uint2*>(d) = hi;
-                    *reinterpret_cast<uint2*>(d + 64) = lo;
-                }
-            }
-        }
+        bconv_stage_halo<NTHR>(p, x, halo, cc, n, ih0, iw0, tid);
         __syncthreads();
         load_a(f0, tap_lo);
 #pragma unroll
@@ -226,29 +283,129 @@ __global__ __launch_bounds__(WAVES * 64) void bconv_kernel(const IgemmParams p, 
         }
     }
 
-    const int Hp = p.Hp[0], Wp = p.Wp[0];
-    const int64_t npix_total = (int64_t)p.N * p.Hc * p.Wc;
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         const int phe = x.phase_split ? ph_z : ph;
-        const int phh = phe / p.so_w, phw = phe % p.so_w;
+        bconv_store_tile<MT, NT>(p, x, acc[ph], wave, lane, n, oh0, ow0, n0, phe / p.so_w, phe % p.so_w, zks);
+    }
+}
+
+// Single-phase variant with the tap loop fully unrolled (NTAPS = 25 or 9 is a template parameter):
+//   * filter fragments travel in a ring of U register sets (U divides NTAPS, so the slot of a tap is a compile-time
+//     constant in every chunk): the load for tap t+U-1 is issued when tap t starts -- U-1 taps (~1.5k cycles at 64
+//     pixels per wave) of L2 latency cover instead of one;
+//   * the activation fragments have ONE register set: each (pixel group, k-step) pair is refilled for the next tap
+//     right behind the three MFMAs that consumed it, which leaves the rest of the tap to cover the LDS latency;
+//   * tap offsets are compile-time indexed scalars: no scalar loads or waits inside the loop.
+template <int NTAPS, int U, int MT, int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void bconvu_kernel(const IgemmParams p, const HconvExtra x, const uint4* __restrict__ Wf, int ntiles) {
+    static_assert(NTAPS % U == 0, "ring slots must line up across chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char halo[];
+    constexpr int NTHR = WAVES * 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int n0 = blockIdx.y * 32 * NT;
+    const int zks = (int)blockIdx.z;                     // chunk-split index (grid.z = ksplit)
+
+    int lane_base[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int pidx = (wave * MT + m) * 32 + li;
+        const int g = pidx >> x.img_shift, pr = pidx & ((1 << x.img_shift) - 1);
+        const int tr = pr >> x.tw_shift, tc = pr & (x.TW - 1);
+        lane_base[m] = (g * x.HRi + tr * p.sa_h) * x.row_bytes + tc * p.sa_w * BC_PIXB + lh * 16;
+    }
+    int toff[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+        toff[t] = (p.taps[t].dh - x.dh_min) * x.row_bytes + (p.taps[t].dw - x.dw_min) * BC_PIXB;
+
+    f32x16 acc[MT][NT];
+
+    const int cc_begin = (x.chunks * zks) / x.ksplit, cc_end = (x.chunks * (zks + 1)) / x.ksplit;
+    const int total_seq = (cc_end - cc_begin) * NTAPS;
+
+    struct BSet { uint4 b[NT][2][2]; };
+    BSet ring[U];
+    uint4 a[MT][2][2];
+    const uint4* wf_lane = Wf + (int64_t)(blockIdx.y * NT) * 256 + lane;
+    auto load_b = [&](BSet& f, int seq) {
+        seq = seq < total_seq ? seq : total_seq - 1;
+        const int cq = seq / NTAPS;
+        const int cc = cc_begin + cq;
+        const int t = seq - cq * NTAPS;
+        const uint4* src = wf_lane + ((int64_t)t * x.chunks + cc) * ntiles * 256;
+#pragma unroll
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f.b[y][s][0] = src[(y * 4 + s * 2) * 64];
+                f.b[y][s][1] = src[(y * 4 + s * 2 + 1) * 64];
+            }
+    };
+    // workgroups walk the tile list with stride gridDim.x (the host launches about two workgroups per CU): the
+    // per-workgroup start-up cost is paid once, and co-resident workgroups drift out of phase so that one's
+    // staging / stores overlap the other's MFMAs
+    const int total_tiles = x.n_tiles;
+    bool first = true;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    int bq = tile;
+    const int tw_i = bq % x.tiles_w; bq /= x.tiles_w;
+    const int th_i = bq % x.tiles_h;
+    const int n = (bq / x.tiles_h) * x.G;
+    const int oh0 = th_i * x.TH, ow0 = tw_i * x.TW;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][y][r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u) load_b(ring[u], u);
+
+    const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = ow0 * p.sa_w + x.dw_min;
+    int seq0 = 0;
+    for (int cc = cc_begin; cc < cc_end; ++cc, seq0 += NTAPS) {
+        if (cc > cc_begin || !first) __syncthreads();
+        first = false;
+        bconv_stage_halo<NTHR>(p, x, halo, cc, n, ih0, iw0, tid);
+        __syncthreads();
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int y = 0; y < NT; ++y) {
-                const int col = n0 + y * 32 + li;
+            for (int s = 0; s < 2; ++s) {
+                const unsigned char* ap = halo + lane_base[m] + toff[0] + s * 32;
+                a[m][s][0] = *reinterpret_cast<const uint4*>(ap);
+                a[m][s][1] = *reinterpret_cast<const uint4*>(ap + 64);
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q = (wave * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int g = q >> x.img_shift, qr = q & ((1 << x.img_shift) - 1);
-                    const int ohp = oh0 + (qr >> x.tw_shift), owp = ow0 + (qr & (x.TW - 1));
-                    if (n + g < p.N && ohp < Hp && owp < Wp && col < p.Cc) {
-                        const int64_t pix = (int64_t)((n + g) * p.Hc + ohp * p.so_h + phh) * p.Wc + owp * p.so_w + phw;
-                        if (x.ksplit > 1) p.Part[((int64_t)zks * npix_total + pix) * p.Cc + col] = acc[ph][m][y][r];
-                        else p.Out[pix * p.c_ld + col] = epilogue_value(p, acc[ph][m][y][r], pix, col);
+        for (int t = 0; t < NTAPS; ++t) {
+            load_b(ring[(t + U - 1) % U], seq0 + t + U - 1);
+            const BSet& f = ring[t % U];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, a[m][s][0]), al = __builtin_bit_cast(bf16x8, a[m][s][1]);
+#pragma unroll
+                    for (int y = 0; y < NT; ++y) {
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, f.b[y][s][0]), bl = __builtin_bit_cast(bf16x8, f.b[y][s][1]);
+                        acc[m][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m][y], 0, 0, 0);
+                        acc[m][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m][y], 0, 0, 0);
+                        acc[m][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m][y], 0, 0, 0);
+                    }
+                    if (t + 1 < NTAPS) {
+                        const unsigned char* ap = halo + lane_base[m] + toff[t + 1 < NTAPS ? t + 1 : t] + s * 32;
+                        a[m][s][0] = *reinterpret_cast<const uint4*>(ap);
+                        a[m][s][1] = *reinterpret_cast<const uint4*>(ap + 64);
                     }
                 }
-            }
+        }
+    }
+
+    bconv_store_tile<MT, NT>(p, x, acc, wave, lane, n, oh0, ow0, n0, 0, 0, zks);
     }
 }
 
@@ -256,6 +413,9 @@ __global__ __launch_bounds__(WAVES * 64) void bconv_kernel(const IgemmParams p, 
 // With 144-byte pixels that holds inside a tile row; across tile rows it needs the row stride
 // = 0 (mod 256 B) for 16-pixel rows and = 128 (mod 256 B) for 8-pixel rows (MI355X_MICROARCH.md, LDS lane groups).
 void bconv_set_rows(HconvExtra* x) {
+    // exact for dividends < 2^20 / divisor (halo pixel indices stay below a few thousand)
+    x->inv_hc = ((1 << 20) + x->HC - 1) / x->HC;
+    x->inv_hri = x->HRi > 0 ? ((1 << 20) + x->HRi - 1) / x->HRi : 0;
     int rb = x->HC * BC_PIXB;
     if (x->TW == 16) rb = (rb + 255) & ~255;
     else if (x->TW == 8) rb = ((rb + 127) & ~255) + 128;
@@ -286,24 +446,46 @@ static int launch_bconv_t(const IgemmParams& p, const HconvExtra& x, dim3 grid, 
     });
 }
 
-int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid,
-                 void* wfrag, void* stream, const char* name, const char* who, double flops, double bytes) {
-    const int nph = p.so_h * p.so_w;
-    const int ntaps = p.tap_begin[nph];
-    const int chunks = x.chunks, ntiles = cdiv(p.Cc, 32 * NT) * NT;
-    uint4* wf = reinterpret_cast<uint4*>(wfrag);
-    {
-        const int64_t threads = (int64_t)ntaps * chunks * ntiles * 2 * 64;
-        const int blocks = (int)cdiv64(threads, 256);
-        const IgemmParams pc = p;
-        int rc = dispatch(stream, OpInfo{"bconv_split_filter", 0.0, 2.0 * (double)ntaps * p.Ka * p.Cc * 4.0}, [=](hipStream_t s) {
-            bconv_split_filter_kernel<<<blocks, 256, 0, s>>>(pc, wf, ntaps, chunks, ntiles);
-            return launched("bconv_split_filter_kernel");
-        });
-        if (rc != MV3D_OK) return rc;
+template <int NTAPS, int U, int MT, int NT, int WAVES>
+static int launch_bconvu_t(const IgemmParams& p, const HconvExtra& x, dim3 grid, size_t lds, const uint4* wf, int ntiles, void* stream,
+                           const char* name, const char* who, double flops, double bytes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bconvu_kernel<NTAPS, U, MT, NT, WAVES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
     }
-    const size_t lds = (size_t)bconv_lds_bytes(x);
+    HconvExtra xp = x;
+    xp.n_tiles = (int)grid.x;
+    static int wg_per_cu = -1;
+    if (wg_per_cu < 0) { const char* e = getenv("MV3D_BC_PERSIST"); wg_per_cu = e ? atoi(e) : 2; }
+    dim3 pg = grid;
+    if (wg_per_cu > 0) {
+        const int by_lds = std::max(1, (int)((160 * 1024) / std::max<size_t>(lds, 1)));
+        const int per_cu = std::min(wg_per_cu, by_lds);
+        const int cap = std::max(1, 256 * per_cu / (int)(grid.y * grid.z));
+        pg.x = std::min<int>((int)grid.x, cap);
+    }
+    return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
+        bconvu_kernel<NTAPS, U, MT, NT, WAVES><<<pg, WAVES * 64, lds, s>>>(p, xp, wf, ntiles);
+        return launched(who);
+    });
+}
+
+static int launch_bconv_cfg(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid, size_t lds,
+                            const uint4* wf, int ntiles, void* stream, const char* name, const char* who, double flops, double bytes) {
 #define MV3D_BC(NPH_, MT_, NT_, W_) launch_bconv_t<NPH_, MT_, NT_, W_>(p, x, grid, lds, wf, ntiles, stream, name, who, flops, bytes)
+    const int ntaps_all = p.tap_begin[p.so_h * p.so_w];
+    if (nph_fused == 1 && !x.phase_split && p.so_h == 1 && p.so_w == 1 && (ntaps_all == 25 || ntaps_all == 9) && !(disabled_paths() & 8192)) {
+#define MV3D_BCU(MT_, NT_, W_) (ntaps_all == 25 ? launch_bconvu_t<25, 5, MT_, NT_, W_>(p, x, grid, lds, wf, ntiles, stream, name, who, flops, bytes) \
+                                                : launch_bconvu_t<9, 3, MT_, NT_, W_>(p, x, grid, lds, wf, ntiles, stream, name, who, flops, bytes))
+        if (MT == 2 && NT == 1 && WAVES == 4) return MV3D_BCU(2, 1, 4);
+        if (MT == 2 && NT == 2 && WAVES == 4) return MV3D_BCU(2, 2, 4);
+        if (MT == 1 && NT == 2 && WAVES == 4) return MV3D_BCU(1, 2, 4);
+        if (MT == 1 && NT == 1 && WAVES == 4) return MV3D_BCU(1, 1, 4);
+        if (MT == 1 && NT == 1 && WAVES == 2) return MV3D_BCU(1, 1, 2);
+#undef MV3D_BCU
+    }
     if (nph_fused == 4) {
         if (MT == 1 && NT == 1 && WAVES == 4) return MV3D_BC(4, 1, 1, 4);
         if (MT == 1 && NT == 1 && WAVES == 2) return MV3D_BC(4, 1, 1, 2);
@@ -318,4 +500,172 @@ int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int M
     return fail(MV3D_E_UNSUPPORTED, "%s: no split-bf16 kernel for nph=%d MT=%d NT=%d waves=%d", who, nph_fused, MT, NT, WAVES);
 }
 
+const void* bconv_cache_lookup(const IgemmParams& p, int* ntiles_out);
+
+int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid,
+                 void* wfrag, void* stream, const char* name, const char* who, double flops, double bytes) {
+    const int nph = p.so_h * p.so_w;
+    const int ntaps = p.tap_begin[nph];
+    const int chunks = x.chunks, ntiles = cdiv(p.Cc, 32 * NT) * NT;
+    uint4* wf = reinterpret_cast<uint4*>(wfrag);
+    int cached_tiles = 0;
+    const void* cached = bconv_cache_lookup(p, &cached_tiles);
+    if (cached && cached_tiles >= ntiles) {
+        wf = reinterpret_cast<uint4*>(const_cast<void*>(cached));
+        const size_t lds0 = (size_t)bconv_lds_bytes(x);
+        return launch_bconv_cfg(p, x, nph_fused, MT, NT, WAVES, grid, lds0, wf, cached_tiles, stream, name, who, flops, bytes);
+    }
+    {
+        const int64_t threads = (int64_t)ntaps * chunks * ntiles * 2 * 64;
+        const int blocks = (int)cdiv64(threads, 256);
+        const IgemmParams pc = p;
+        int rc = dispatch(stream, OpInfo{"bconv_split_filter", 0.0, 2.0 * (double)ntaps * p.Ka * p.Cc * 4.0}, [=](hipStream_t s) {
+            bconv_split_filter_kernel<<<blocks, 256, 0, s>>>(pc, wf, ntaps, chunks, ntiles);
+            return launched("bconv_split_filter_kernel");
+        });
+        if (rc != MV3D_OK) return rc;
+    }
+    return launch_bconv_cfg(p, x, nph_fused, MT, NT, WAVES, grid, (size_t)bconv_lds_bytes(x), wf, ntiles, stream, name, who, flops, bytes);
+}
+
+
+// ---- prepared-filter cache ------------------------------------------------------------------------
+// A caller that knows a set of filters stays constant over several convolution calls (a training step:
+// every filter is used by the forward pass and again, in the other orientation, by the backward-data pass)
+// binds a caller-owned buffer per (filter, orientation); mv3d_filter_cache_refresh() then re-splits ALL bound
+// filters in one launch and the convolution calls that find their filter in the cache skip their own split
+// launch.  Unbound filters keep working (split per call into the workspace).
+struct SplitJob {
+    const float* Wt; uint4* Wf;
+    int ntaps, chunks, ntiles, Ka, Cc, w_tap_stride, w_ks, w_ns;
+    int first_block, nblocks;
+    int16_t widx[36];
+};
+
+static std::mutex g_cache_mu;
+static std::vector<SplitJob> g_jobs;
+static const SplitJob* g_table_dev = nullptr;
+static int g_table_jobs = 0, g_total_blocks = 0;
+
+__global__ __launch_bounds__(256) void bconv_split_all_kernel(const SplitJob* __restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;      // block-uniform
+    const SplitJob jb = jobs[j];
+    const int64_t gid = (int64_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    int64_t r = gid >> 6;
+    const int s = (int)(r & 1); r >>= 1;
+    const int nt = (int)(r % jb.ntiles); r /= jb.ntiles;
+    const int cc = (int)(r % jb.chunks); r /= jb.chunks;
+    const int t = (int)r;
+    if (t >= jb.ntaps) return;
+    const int li = lane & 31, lh = lane >> 5;
+    const int col = nt * 32 + li;
+    const int ch0 = cc * 32 + s * 16 + lh * 8;
+    const float* wt = jb.Wt + (int64_t)jb.widx[t] * jb.w_tap_stride;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = ch0 + e;
+        v[e] = (col < jb.Cc && ch < jb.Ka) ? wt[(int64_t)ch * jb.w_ks + (int64_t)col * jb.w_ns] : 0.f;
+    }
+    uint2 h0, l0, h1, l1;
+    split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+    split4(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+    uint4* dst = jb.Wf + ((((int64_t)t * jb.chunks + cc) * jb.ntiles + nt) * 4 + s * 2) * 64 + lane;
+    dst[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    dst[64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+static bool job_matches(const SplitJob& j, const IgemmParams& p, int ntaps) {
+    if (j.Wt != p.Wt || j.ntaps != ntaps || j.Ka != p.Ka || j.Cc != p.Cc || j.w_ks != p.w_ks || j.w_ns != p.w_ns ||
+        j.w_tap_stride != p.w_tap_stride) return false;
+    for (int t = 0; t < ntaps; ++t) if (j.widx[t] != p.taps[t].widx) return false;
+    return true;
+}
+
+// prepared copy of p's filter, or null; *ntiles_out = column-tile count of its layout
+const void* bconv_cache_lookup(const IgemmParams& p, int* ntiles_out) {
+    const int ntaps = p.tap_begin[p.so_h * p.so_w];
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (!g_table_dev) return nullptr;                 // never committed: the buffers hold nothing yet
+    for (int i = 0; i < g_table_jobs && i < (int)g_jobs.size(); ++i)
+        if (job_matches(g_jobs[i], p, ntaps)) { *ntiles_out = g_jobs[i].ntiles; return g_jobs[i].Wf; }
+    return nullptr;
+}
+
+size_t bconv_prepared_bytes(const IgemmParams& p) {
+    if (p.fold || p.Ka % 16 != 0 || p.Cc < 16) return 0;
+    const int ntaps = p.tap_begin[p.so_h * p.so_w];
+    if (ntaps < 2 || ntaps > 36) return 0;
+    return bconv_filter_bytes(p, 2);
+}
+
+int bconv_cache_bind(const IgemmParams& p, void* prepared, size_t bytes) {
+    const size_t need = bconv_prepared_bytes(p);
+    if (need == 0) return 1;                          // this operation never uses a prepared filter
+    if (!prepared || bytes < need || (reinterpret_cast<uintptr_t>(prepared) & 15))
+        return fail(MV3D_E_INVAL, "mv3d_filter_cache_bind: prepared buffer null, misaligned or %zu < %zu bytes", bytes, need);
+    const int ntaps = p.tap_begin[p.so_h * p.so_w];
+    SplitJob j = {};
+    j.Wt = p.Wt; j.Wf = reinterpret_cast<uint4*>(prepared);
+    j.ntaps = ntaps; j.chunks = cdiv(p.Ka, 32); j.ntiles = cdiv(p.Cc, 64) * 2; j.Ka = p.Ka; j.Cc = p.Cc;
+    j.w_tap_stride = p.w_tap_stride; j.w_ks = p.w_ks; j.w_ns = p.w_ns;
+    for (int t = 0; t < ntaps; ++t) j.widx[t] = p.taps[t].widx;
+    j.nblocks = (int)cdiv64((int64_t)ntaps * j.chunks * j.ntiles * 2 * 64, 256);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto& e : g_jobs)
+        if (job_matches(e, p, ntaps)) { e.Wf = j.Wf; g_table_dev = nullptr; return MV3D_OK; }
+    g_jobs.push_back(j);
+    g_table_dev = nullptr;                            // table must be committed again
+    return MV3D_OK;
+}
+
 }  // namespace mv3d
+
+using namespace mv3d;
+
+extern "C" {
+
+size_t mv3d_filter_cache_table_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    return g_jobs.size() * sizeof(SplitJob);
+}
+
+int mv3d_filter_cache_commit(void* table_dev, size_t table_bytes, void* stream) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    const size_t need = g_jobs.size() * sizeof(SplitJob);
+    if (g_jobs.empty()) { g_table_dev = nullptr; g_table_jobs = 0; g_total_blocks = 0; return MV3D_OK; }
+    if (!table_dev || table_bytes < need) return fail(MV3D_E_INVAL, "mv3d_filter_cache_commit: table %zu < %zu bytes", table_bytes, need);
+    int first = 0;
+    for (auto& j : g_jobs) { j.first_block = first; first += j.nblocks; }
+    hipError_t e = hipMemcpyAsync(table_dev, g_jobs.data(), need, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));      // g_jobs may be edited right after
+    if (e != hipSuccess) return fail(MV3D_E_HIP, "mv3d_filter_cache_commit: %s", hipGetErrorString(e));
+    g_table_dev = reinterpret_cast<const SplitJob*>(table_dev);
+    g_table_jobs = (int)g_jobs.size();
+    g_total_blocks = first;
+    return MV3D_OK;
+}
+
+int mv3d_filter_cache_refresh(void* stream) {
+    const SplitJob* table; int njobs, blocks; double bytes = 0.0;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        table = g_table_dev; njobs = g_table_jobs; blocks = g_total_blocks;
+        for (int i = 0; i < njobs; ++i) bytes += 8.0 * g_jobs[i].ntaps * (double)g_jobs[i].Ka * g_jobs[i].Cc;
+    }
+    if (!table || njobs == 0) return MV3D_OK;
+    return dispatch(stream, OpInfo{"bconv_split_all", 0.0, bytes}, [=](hipStream_t s) {
+        bconv_split_all_kernel<<<blocks, 256, 0, s>>>(table, njobs);
+        return launched("bconv_split_all_kernel");
+    });
+}
+
+int mv3d_filter_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_jobs.clear(); g_table_dev = nullptr; g_table_jobs = 0; g_total_blocks = 0;
+    return MV3D_OK;
+}
+
+}  // extern "C"

@@ -751,17 +751,11 @@ static inline double conv_bytes(const mv3d_conv_geom* g) {
 }
 
 // image side -> feature side (conv fwd / deconv dgrad)
-static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, void* feat, const mv3d_epilogue* epi,
-                    void* ws, size_t ws_bytes, void* stream, const char* who) {
-    int rc = check_geom(g, who);
-    if (rc == MV3D_OK) rc = check_epilogue(epi, who);
-    if (rc != MV3D_OK) return rc;
-    if (!img || !w || !feat) return fail(MV3D_E_INVAL, "%s: null tensor pointer", who);
-    IgemmParams p = {};
+// Geometry / tap table / filter strides of the image -> feature direction (conv fwd, deconv dgrad); no pointers.
+static void i2f_params(const mv3d_conv_geom* g, IgemmParams& p, int* pt_out, int* pl_out) {
     int ho, wo, pt, pl;
     same_pad(g->H, g->kh, g->sh, &ho, &pt);
     same_pad(g->W, g->kw, g->sw, &wo, &pl);
-    p.A = (const float*)img; p.Wt = (const float*)w; p.Out = (float*)feat;
     p.N = g->N; p.Ha = g->H; p.Wa = g->W; p.Ca = g->C; p.a_ld = g->img_ld;
     p.Hc = g->Ho; p.Wc = g->Wo; p.Cc = g->K; p.c_ld = g->feat_ld;
     p.sa_h = g->sh; p.sa_w = g->sw; p.so_h = 1; p.so_w = 1;
@@ -778,6 +772,19 @@ static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, voi
     }
     p.tap_begin[0] = 0; p.tap_begin[1] = nt;
     p.w_tap_stride = g->C * g->K; p.w_ks = g->K; p.w_ns = 1;
+    *pt_out = pt; *pl_out = pl;
+}
+
+static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, void* feat, const mv3d_epilogue* epi,
+                    void* ws, size_t ws_bytes, void* stream, const char* who) {
+    int rc = check_geom(g, who);
+    if (rc == MV3D_OK) rc = check_epilogue(epi, who);
+    if (rc != MV3D_OK) return rc;
+    if (!img || !w || !feat) return fail(MV3D_E_INVAL, "%s: null tensor pointer", who);
+    IgemmParams p = {};
+    int pt, pl;
+    i2f_params(g, p, &pt, &pl);
+    p.A = (const float*)img; p.Wt = (const float*)w; p.Out = (float*)feat;
     fill_epilogue(p, epi);
     if (p.fold && g->C <= 4 && g->kw * g->C <= 20 && g->K <= 64 && !(disabled_paths() & 64)) {
         SmallCParams q = {};
@@ -797,18 +804,11 @@ static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, voi
     return run_igemm(p, ws, ws_bytes, stream, who, conv_flops(g), conv_bytes(g));
 }
 
-// feature side -> image side (conv dgrad / deconv fwd), one dense sub-convolution per stride phase
-static int feat2img(const mv3d_conv_geom* g, const void* feat, const void* w, void* img, const mv3d_epilogue* epi,
-                    void* ws, size_t ws_bytes, void* stream, const char* who) {
-    int rc = check_geom(g, who);
-    if (rc == MV3D_OK) rc = check_epilogue(epi, who);
-    if (rc != MV3D_OK) return rc;
-    if (!img || !w || !feat) return fail(MV3D_E_INVAL, "%s: null tensor pointer", who);
-    IgemmParams p = {};
+// Same for the feature -> image direction (conv dgrad, deconv fwd): one dense sub-convolution per stride phase.
+static void f2i_params(const mv3d_conv_geom* g, IgemmParams& p) {
     int ho, wo, pt, pl;
     same_pad(g->H, g->kh, g->sh, &ho, &pt);
     same_pad(g->W, g->kw, g->sw, &wo, &pl);
-    p.A = (const float*)feat; p.Wt = (const float*)w; p.Out = (float*)img;
     p.N = g->N; p.Ha = g->Ho; p.Wa = g->Wo; p.Ca = g->K; p.a_ld = g->feat_ld;
     p.Hc = g->H; p.Wc = g->W; p.Cc = g->C; p.c_ld = g->img_ld;
     p.sa_h = 1; p.sa_w = 1; p.so_h = g->sh; p.so_w = g->sw;
@@ -833,6 +833,18 @@ static int feat2img(const mv3d_conv_geom* g, const void* feat, const void* w, vo
     p.tap_begin[g->sh * g->sw] = nt;
     p.fold = 0; p.Ka = g->K;
     p.w_tap_stride = g->C * g->K; p.w_ks = 1; p.w_ns = g->K;
+}
+
+// feature side -> image side (conv dgrad / deconv fwd), one dense sub-convolution per stride phase
+static int feat2img(const mv3d_conv_geom* g, const void* feat, const void* w, void* img, const mv3d_epilogue* epi,
+                    void* ws, size_t ws_bytes, void* stream, const char* who) {
+    int rc = check_geom(g, who);
+    if (rc == MV3D_OK) rc = check_epilogue(epi, who);
+    if (rc != MV3D_OK) return rc;
+    if (!img || !w || !feat) return fail(MV3D_E_INVAL, "%s: null tensor pointer", who);
+    IgemmParams p = {};
+    f2i_params(g, p);
+    p.A = (const float*)feat; p.Wt = (const float*)w; p.Out = (float*)img;
     fill_epilogue(p, epi);
     return run_igemm(p, ws, ws_bytes, stream, who, conv_flops(g), conv_bytes(g));
 }
@@ -957,6 +969,31 @@ int mv3d_deconv2d_dgrad(const mv3d_conv_geom* g, const void* dy, const void* w, 
 }
 int mv3d_deconv2d_wgrad(const mv3d_conv_geom* g, const void* x, const void* dy, void* dw, void* ws, size_t wsb, void* stream) {
     return filtgrad(g, dy, x, dw, nullptr, ws, wsb, stream, "mv3d_deconv2d_wgrad");
+}
+
+static bool filter_op_params(const mv3d_conv_geom* g, int op, const void* w, IgemmParams& p, const char* who) {
+    if (!g || check_geom(g, who) != MV3D_OK) return false;
+    if (op == MV3D_FILTER_CONV_FWD || op == MV3D_FILTER_DECONV_DGRAD) { int pt, pl; i2f_params(g, p, &pt, &pl); }
+    else if (op == MV3D_FILTER_CONV_DGRAD || op == MV3D_FILTER_DECONV_FWD) f2i_params(g, p);
+    else { fail(MV3D_E_INVAL, "%s: unknown filter operation %d", who, op); return false; }
+    p.Wt = (const float*)w;
+    return true;
+}
+
+size_t mv3d_filter_prepared_bytes(const mv3d_conv_geom* g, int op) {
+    IgemmParams p = {};
+    if (!filter_op_params(g, op, nullptr, p, "mv3d_filter_prepared_bytes")) return 0;
+    if (disabled_paths() & (1 | 4096)) return 0;
+    return bconv_prepared_bytes(p);
+}
+
+int mv3d_filter_cache_bind(const mv3d_conv_geom* g, int op, const void* w, void* prepared, size_t prepared_bytes) {
+    IgemmParams p = {};
+    if (!w) return fail(MV3D_E_INVAL, "mv3d_filter_cache_bind: null filter pointer");
+    if (!filter_op_params(g, op, w, p, "mv3d_filter_cache_bind")) return MV3D_E_INVAL;
+    int rc = bconv_cache_bind(p, prepared, prepared_bytes);
+    if (rc == 1) return fail(MV3D_E_UNSUPPORTED, "mv3d_filter_cache_bind: this operation does not take a prepared filter");
+    return rc;
 }
 
 size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g) {

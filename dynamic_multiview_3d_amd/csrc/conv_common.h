@@ -47,6 +47,8 @@ struct HconvExtra {
     int HRi;             // halo rows per image (HR = G * HRi)
     int ksplit;          // channel chunks are split over grid.z; raw partial sums go to p.Part, igemm_splitk_epilogue finishes
     int dbg;             // MV3D_DBG diagnostics: 1 = no halo loads, 8 = skip the tap loop
+    int inv_hc, inv_hri; // bconv: ceil(2^20 / HC), ceil(2^20 / HRi) -- divisions by multiply + shift in the staging loops
+    int n_tiles;         // bconvu: number of spatial tiles (workgroups walk them with stride gridDim.x)
     int row_bytes;       // bconv (split-bf16) kernels: LDS bytes per halo row (padded for conflict-free 16-byte reads)
 };
 
@@ -66,6 +68,8 @@ int try_fc_stream(bool trans, int B, int in, int out, const void* x, int x_ld, c
 //   launch_bconv: filter split + main kernel (2 launches); nph 1|4, MT/NT register blocking, 2 or 4 waves
 size_t bconv_filter_bytes(const IgemmParams& p, int NT);
 int bconv_lds_bytes(const HconvExtra& x);
+size_t bconv_prepared_bytes(const IgemmParams& p);        // 0: this problem never uses a prepared filter
+int bconv_cache_bind(const IgemmParams& p, void* prepared, size_t bytes);
 void bconv_set_rows(HconvExtra* x);
 int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid,
                  void* wfrag, void* stream, const char* name, const char* who, double flops, double bytes);

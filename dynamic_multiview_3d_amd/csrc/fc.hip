@@ -163,8 +163,9 @@ __global__ __launch_bounds__(256) void fc_stream_b3_kernel(const FcParams p) {
     const int colc = col < p.N ? col : p.N - 1;
 
     constexpr int A_PASSES = ROWS / 32;
-    float4 ra[A_PASSES];
-    auto load_a = [&](int chunk) {
+    constexpr int RING = MT <= 2 ? 6 : 4;
+    float4 rq[RING][A_PASSES];
+    auto load_a = [&](float4 (&ra)[A_PASSES], int chunk) {
         const int r0 = chunk * 32 + (tid & 7) * 4;
         const bool k_ok = r0 + 4 <= p.R;
 #pragma unroll
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void fc_stream_b3_kernel(const FcParams p) {
             ra[ps] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](const float4 (&ra)[A_PASSES], int buf) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps) {
             uint2 hi, lo;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void fc_stream_b3_kernel(const FcParams p) {
         }
     };
     // lane half lh holds reduction indices r0 + lh*16 .. +15 of its column (k-step s uses elements 8s..8s+7)
-    float bq[3][16];
+    float bq[RING][16];
     auto load_b = [&](float (&b)[16], int chunk) {
         const int r0 = chunk * 32 + lh * 16;
         const int rc = (r0 + 16 <= p.R) ? r0 : 0;          // past-the-end group: valid dummy (its A columns are zero)
@@ -224,24 +225,28 @@ __global__ __launch_bounds__(256) void fc_stream_b3_kernel(const FcParams p) {
     };
 
     if (c_begin < c_end) {
-        load_a(c_begin);
-        load_b(bq[0], c_begin);
-        load_b(bq[1], c_begin + 1 < c_end ? c_begin + 1 : c_begin);
-        store_a(0);
+        // chunk c in use, c+1 .. c+RING-1 in flight (activations and weights of a chunk are requested together, so
+        // waiting for chunk c+1's activations never waits for younger weight loads: vmcnt retires in order);
+        // unrolled by RING so every register-set index is a compile-time constant
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u) {
+            const int cu = c_begin + u < c_end ? c_begin + u : c_end - 1;
+            load_a(rq[u], cu);
+            load_b(bq[u], cu);
+        }
+        store_a(rq[0], 0);
         __syncthreads();
         int buf = 0;
-        // weights: three register sets rotate (chunk c in use, c+1 and c+2 in flight); unrolled by 3 so the
-        // set index is a compile-time constant
-        for (int c = c_begin; c < c_end; c += 3) {
+        for (int c = c_begin; c < c_end; c += RING) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < RING; ++u) {
                 const int cc = c + u;
                 if (cc < c_end) {
-                    const bool more = cc + 1 < c_end;
-                    if (more) load_a(cc + 1);
-                    load_b(bq[(u + 2) % 3], cc + 2 < c_end ? cc + 2 : c_end - 1);
+                    const int cn = cc + RING - 1 < c_end ? cc + RING - 1 : c_end - 1;
+                    load_a(rq[(u + RING - 1) % RING], cn);
+                    load_b(bq[(u + RING - 1) % RING], cn);
                     mma(bq[u], buf);
-                    if (more) store_a(buf ^ 1);
+                    if (cc + 1 < c_end) store_a(rq[(u + 1) % RING], buf ^ 1);
                     __syncthreads();
                     buf ^= 1;
                 }
@@ -458,10 +463,16 @@ static bool fc_stream_ok(int B, int in, int out, const void* x, int x_ld, const 
     return !(disabled_paths() & 16);
 }
 
+static int fc_target_wgs() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MV3D_FC_WGS"); v = e ? atoi(e) : 256; }
+    return v;
+}
+
 size_t fc_stream_ws_bytes(int B, int in, int out, bool trans) {
     const int R = trans ? out : in, N = trans ? in : out;
     const int chunks = cdiv(R, 32);
-    int nsplit = std::max(1, std::min(chunks / 4, cdiv(640, cdiv(N, 128))));
+    int nsplit = std::max(1, std::min(chunks / 4, cdiv(fc_target_wgs(), cdiv(N, 128))));
     return (size_t)nsplit * B * N * sizeof(float);
 }
 
@@ -474,7 +485,7 @@ int try_fc_stream(bool trans, int B, int in, int out, const void* x, int x_ld, c
     p.X = (const float*)x; p.W = (const float*)W; p.Part = (float*)ws;
     p.M = B; p.R = trans ? out : in; p.N = trans ? in : out; p.x_ld = x_ld; p.w_ld = out;
     p.chunks_total = cdiv(p.R, 32);
-    p.nsplit = std::max(1, std::min(p.chunks_total / 4, cdiv(640, cdiv(p.N, 128))));
+    p.nsplit = std::max(1, std::min(p.chunks_total / 4, cdiv(fc_target_wgs(), cdiv(p.N, 128))));
     const size_t need = (size_t)p.nsplit * B * p.N * sizeof(float);
     if (!ws || wsb < need) return 1;
     dim3 grid(cdiv(p.N, 128), p.nsplit);

@@ -603,6 +603,9 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
                                         {64, 1, 1, 2, "bconv<1ph,64px,N32>"}};
                 for (int c = 0; c < 5; ++c) {
                     const Cand& cd = ladder[c];
+                    static int maxpix = -1;
+                    if (maxpix < 0) { const char* e = getenv("MV3D_BC_MAXPIX"); maxpix = e ? atoi(e) : 256; }
+                    if (cd.pix > maxpix) continue;
                     if (cd.pix == 256 && Hp * Wp < 256) continue;
                     HconvExtra x = {};
                     if (!pick_tile(p, cd.pix, Hp, Wp, dh_span, dw_span, 78 * 1024, &x, true)) continue;

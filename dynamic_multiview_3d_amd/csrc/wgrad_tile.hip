@@ -31,6 +31,7 @@ struct WgTileParams {
     int ctiles;
     int ntiles_total, tiles_per_slab;
     int b3;              // 1: split-bf16 kernel (wgrad_b3_kernel)
+    int inv_hc, tpix8_shift;   // ceil(2^20 / HC); log2(TPIX * 8)
 };
 
 __device__ float4 g_zero16[4];        // 64 bytes of zeros in the code object: source of out-of-image LDS-DMA lanes
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
         for (int j = 0; j < NI; ++j) {
             const int idx = j * 512 + tid;
             const int pix = idx >> 3, c4 = idx & 7;
-            const int hr = pix / p.HC, hc = pix - hr * p.HC;
+            const int hr = (int)(((unsigned)pix * (unsigned)p.inv_hc) >> 20), hc = pix - hr * p.HC;
             const int ih = ih0 + hr, iwc = iw0 + hc, ch = c0 + c4 * 4;
             const bool ok = idx < n_img4 && (unsigned)ih < (unsigned)p.H && (unsigned)iwc < (unsigned)p.W && ch < p.C;
             const float* src = ok ? p.img + (int64_t)((n * p.H + ih) * p.W + iwc) * p.img_ld + ch : p.img;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             const int idx = j * 512 + tid;
-            const int kt = idx / (p.TPIX * 8), rem = idx - kt * (p.TPIX * 8);
+            const int kt = idx >> p.tpix8_shift, rem = idx & ((1 << p.tpix8_shift) - 1);
             const int pq = rem >> 3, c4 = rem & 7;
             const int oh = oh0 + (pq >> p.tw_shift), ow = ow0 + (pq & (p.TW - 1)), kk = k0 + kt * 32 + c4 * 4;
             const bool ok = idx < n_feat4 && oh < p.Ho && ow < p.Wo && kk < p.K;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
             const int idx = j * 512 + tid;
             if (idx < n_img4) {
                 const int pix = idx >> 3, c4 = idx & 7;
-                const int hr = pix / p.HC, hc = pix - hr * p.HC;
+                const int hr = (int)(((unsigned)pix * (unsigned)p.inv_hc) >> 20), hc = pix - hr * p.HC;
                 const int cs = (p.sw == 2) ? (hc & 1) * HCh + (hc >> 1) : hc;
                 unsigned char* d = buf + (hr * p.HC + cs) * 64 + c4 * 8;
                 uint2 hi, lo;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
         for (int j = 0; j < NF; ++j) {
             const int idx = j * 512 + tid;
             if (idx < n_feat4) {
-                const int kt = idx / (p.TPIX * 8), rem = idx - kt * (p.TPIX * 8);
+                const int kt = idx >> p.tpix8_shift, rem = idx & ((1 << p.tpix8_shift) - 1);
                 unsigned char* d = buf + 2 * img_plane + kt * 2 * feat_plane + (rem >> 3) * 64 + (rem & 7) * 8;
                 uint2 hi, lo;
                 wsplit4(vf[j], hi, lo);
@@ -534,6 +535,8 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     if (nslab > p.ntiles_total) nslab = p.ntiles_total;
     p.tiles_per_slab = cdiv(p.ntiles_total, nslab);
     nslab = cdiv(p.ntiles_total, p.tiles_per_slab);
+    p.inv_hc = ((1 << 20) + p.HC - 1) / p.HC;
+    p.tpix8_shift = p.TPIX == 128 ? 10 : 9;
     *out = p;
     *nslab_out = nslab;
     *cfg_out = cfg;

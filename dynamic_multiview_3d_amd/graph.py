@@ -540,9 +540,11 @@ class Graph:
         lib = self.lib
         for t in self.tensors:
             t.grad_written = t.grad_masked = False
+        self._bind_prepared_filters()
         self.plan_fwd = lib.plan_create()
         lib.plan_begin(self.plan_fwd)
         try:
+            lib.filter_cache_refresh(None)      # first launch of the step: convert every conv filter once
             for n in self.nodes:
                 n.forward(self)
             self._emit_losses(with_grad=True)
@@ -582,6 +584,32 @@ class Graph:
         self.n_launch_fwd = lib.plan_size(self.plan_fwd)
         self.n_launch_bwd = lib.plan_size(self.plan_bwd)
         return self
+
+    def _bind_prepared_filters(self):
+        """Weights only change in apply_adam(), so each conv filter is converted to the kernels' operand format
+        once per step (mv3d_filter_cache_*, include/mv3d_hip.h) instead of once per call.  The library's cache is
+        process-global: it is reset here, the plans recorded below keep their own copy of the job table."""
+        lib = self.lib
+        lib.filter_cache_clear()
+        self._prepared = []
+        if torch.device(self.device).type != 'cuda':      # plan recording without a GPU (host-logic tests): nothing to bind
+            return
+        for n in self.nodes:
+            if not isinstance(n, ConvNode):
+                continue
+            geom = n.geom()
+            ops = [2 if n.transposed else 0]
+            if n.x.requires_grad:
+                ops.append(3 if n.transposed else 1)
+            for op in ops:
+                nbytes = int(lib.filter_prepared_bytes(C.byref(geom), op))
+                if nbytes > 0:
+                    buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                    self._prepared.append(buf)
+                    lib.filter_cache_bind(C.byref(geom), op, n.w.ptr, buf.data_ptr(), nbytes)
+        tb = int(lib.filter_cache_table_bytes())
+        self._prepared_table = torch.empty(max(tb, 16), dtype=torch.uint8, device=self.device)
+        lib.filter_cache_commit(self._prepared_table.data_ptr(), tb, None)
 
     # ---------------------------------------------------------------- execution
     def _stream_ptr(self):

@@ -89,6 +89,26 @@ int mv3d_deconv2d_wgrad(const mv3d_conv_geom* g, const void* x, const void* dy, 
 /* bytes of scratch the six calls above may need for this geometry (max over them) */
 size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g);
 
+/* ---- prepared filters (optional) -------------------------------------------------------------
+ * The matrix-core convolution kernels read the filter split into bf16 hi/lo parts in MFMA fragment order.
+ * By default each call converts its filter into the workspace (one extra small launch).  A caller that knows
+ * its filters stay constant over several calls -- the reference's train step uses every filter in the forward
+ * pass and again in the backward-data pass before tf.train.AdamOptimizer updates it (appearance_flow_model.py:77)
+ * -- binds one caller-owned buffer per (filter, operation), commits the job table, and calls
+ * mv3d_filter_cache_refresh() once after every weight update: ONE launch converts all bound filters and the
+ * convolution calls that find their filter pointer in the cache skip their own conversion.
+ * The cache is process-global (guarded by a mutex); the library never frees the bound buffers. */
+enum { MV3D_FILTER_CONV_FWD = 0, MV3D_FILTER_CONV_DGRAD = 1, MV3D_FILTER_DECONV_FWD = 2, MV3D_FILTER_DECONV_DGRAD = 3 };
+/* bytes of the prepared copy for this geometry / operation; 0 = the operation does not take one */
+size_t mv3d_filter_prepared_bytes(const mv3d_conv_geom* g, int op);
+int mv3d_filter_cache_bind(const mv3d_conv_geom* g, int op, const void* w, void* prepared, size_t prepared_bytes);
+/* device bytes of the job table for the current bindings; commit uploads it (synchronises `stream`) */
+size_t mv3d_filter_cache_table_bytes(void);
+int mv3d_filter_cache_commit(void* table_dev, size_t table_bytes, void* stream);
+/* one launch: convert every bound filter (recordable in a plan) */
+int mv3d_filter_cache_refresh(void* stream);
+int mv3d_filter_cache_clear(void);
+
 /* ---- linear: tf.matmul(x, M) + b  (tf_utils.py:67) ------------------------------------------
  * x [B,in] (row stride x_ld), M [in,out] dense, y [B,out] (row stride y_ld). */
 int mv3d_fc_fwd(int B, int in, int out, const void* x, int x_ld, const void* M, void* y, int y_ld,
