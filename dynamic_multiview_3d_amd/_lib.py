@@ -61,6 +61,8 @@ STATUS_FUNCS = {
     "mv3d_plan_end": [],
     "mv3d_plan_run": [_vp, _vp],
     "mv3d_plan_run_range": [_vp, _i, _i, _vp],
+    "mv3d_plan_run_range2": [_vp, _i, _i, _vp, _vp],
+    "mv3d_plan_side": [_i],
     "mv3d_plan_profile": [_vp, _i],
     "mv3d_plan_profile_collect": [_vp],
     "mv3d_plan_profile_select": [_vp, C.c_char_p],

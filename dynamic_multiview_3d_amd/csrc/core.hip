@@ -11,6 +11,7 @@ struct PlanOp {
     double total_ms;
     int runs;
     bool selected = true;      // bracketed with events when profiling
+    int side = 0;              // 1: may run on the side stream of mv3d_plan_run_range2 (see mv3d_plan_side)
 };
 
 struct mv3d_plan {
@@ -18,11 +19,13 @@ struct mv3d_plan {
     bool profile = false;
     std::vector<hipEvent_t> pool;   // 2 events per op per profiled run, collected in bulk
     size_t used = 0;
+    hipEvent_t fork = nullptr, join = nullptr;      // stream dependencies of two-stream runs
 };
 
 namespace mv3d {
 static thread_local char g_err[512] = "";
 static thread_local mv3d_plan* g_rec = nullptr;
+static thread_local int g_side = 0;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -32,12 +35,12 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 bool recording() { return g_rec != nullptr; }
-void record(std::function<int(hipStream_t)> fn, const OpInfo& info) { g_rec->ops.push_back(PlanOp{std::move(fn), info, 0.0, 0, true}); }
+void record(std::function<int(hipStream_t)> fn, const OpInfo& info) { g_rec->ops.push_back(PlanOp{std::move(fn), info, 0.0, 0, true, g_side}); }
 }  // namespace mv3d
 
 extern "C" {
 
-const char* mv3d_version(void) { return "mv3d_hip 0.2 (gfx950, fp32 MFMA)"; }
+const char* mv3d_version(void) { return "mv3d_hip 0.3 (gfx950, split-bf16 / fp32 MFMA)"; }
 const char* mv3d_last_error(void) { return mv3d::g_err; }
 
 mv3d_plan* mv3d_plan_create(void) { return new mv3d_plan(); }
@@ -45,6 +48,8 @@ void mv3d_plan_destroy(mv3d_plan* p) {
     if (!p) return;
     if (mv3d::g_rec == p) mv3d::g_rec = nullptr;
     for (hipEvent_t e : p->pool) (void)hipEventDestroy(e);
+    if (p->fork) (void)hipEventDestroy(p->fork);
+    if (p->join) (void)hipEventDestroy(p->join);
     delete p;
 }
 int mv3d_plan_begin(mv3d_plan* p) {
@@ -53,6 +58,13 @@ int mv3d_plan_begin(mv3d_plan* p) {
     p->ops.clear();
     p->used = 0;
     mv3d::g_rec = p;
+    mv3d::g_side = 0;
+    return MV3D_OK;
+}
+// Launches recorded after mv3d_plan_side(1) (until mv3d_plan_side(0)) are tagged as side work: they depend on
+// everything recorded before them, and nothing recorded later in the same plan range depends on them.
+int mv3d_plan_side(int side) {
+    mv3d::g_side = side ? 1 : 0;
     return MV3D_OK;
 }
 int mv3d_plan_end(void) {
@@ -66,16 +78,48 @@ int mv3d_plan_size(const mv3d_plan* p) { return p ? (int)p->ops.size() : 0; }
 // consecutive ranges (data-parallel training interleaves bucket all-reduces): the event pool slot of
 // op i is (pass base + 2i), and the pass is closed when a range ends at the last op.
 int mv3d_plan_run_range(mv3d_plan* p, int begin, int end, void* stream) {
+    return mv3d_plan_run_range2(p, begin, end, stream, nullptr);
+}
+
+// Two-stream form: side-tagged launches go to `side_stream` behind an event on `stream` (fork at every
+// main -> side transition), `stream` waits for the side stream once at the end of the range (join).
+int mv3d_plan_run_range2(mv3d_plan* p, int begin, int end, void* stream, void* side_stream) {
     if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: null plan");
     if (mv3d::g_rec) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: cannot run while recording");
     const int n = (int)p->ops.size();
     if (begin < 0 || end > n || begin > end) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: bad range [%d, %d) of %d", begin, end, n);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipStream_t s2 = reinterpret_cast<hipStream_t>(side_stream);
+    const bool two = side_stream != nullptr && s2 != s;
+    if (two && !p->fork) {
+        if (hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess)
+            return mv3d::fail(MV3D_E_HIP, "mv3d_plan_run_range2: hipEventCreate failed");
+    }
+    int prev_side = 0;
+    bool side_used = false;
+    auto stream_of = [&](int i) -> hipStream_t {
+        const int sd = two ? p->ops[i].side : 0;
+        if (sd == 1 && prev_side == 0) {                     // fork: side work sees everything issued so far
+            (void)hipEventRecord(p->fork, s);
+            (void)hipStreamWaitEvent(s2, p->fork, 0);
+            side_used = true;
+        }
+        prev_side = sd;
+        return sd ? s2 : s;
+    };
+    auto join = [&]() {
+        if (side_used) {
+            (void)hipEventRecord(p->join, s2);
+            (void)hipStreamWaitEvent(s, p->join, 0);
+        }
+    };
     if (!p->profile) {
         for (int i = begin; i < end; ++i) {
-            int rc = p->ops[i].fn(s);
+            int rc = p->ops[i].fn(stream_of(i));
             if (rc != MV3D_OK) return rc;
         }
+        join();
         return MV3D_OK;
     }
     // profiled run: bracket every launch with HIP events on the launch stream; no host sync here
@@ -87,11 +131,13 @@ int mv3d_plan_run_range(mv3d_plan* p, int begin, int end, void* stream) {
     }
     for (int i = begin; i < end; ++i) {
         const bool sel = p->ops[i].selected;
-        if (sel) (void)hipEventRecord(p->pool[p->used + 2 * i], s);
-        int rc = p->ops[i].fn(s);
-        if (sel) (void)hipEventRecord(p->pool[p->used + 2 * i + 1], s);
+        hipStream_t so = stream_of(i);
+        if (sel) (void)hipEventRecord(p->pool[p->used + 2 * i], so);
+        int rc = p->ops[i].fn(so);
+        if (sel) (void)hipEventRecord(p->pool[p->used + 2 * i + 1], so);
         if (rc != MV3D_OK) return rc;
     }
+    join();
     if (end == n) p->used = need;
     return MV3D_OK;
 }

@@ -20,6 +20,7 @@ Data layout in HBM
 PyTorch is used for device memory (torch.empty), streams and torch.distributed only.
 """
 import ctypes as C
+import os
 import math
 from collections import OrderedDict
 
@@ -244,11 +245,14 @@ class ConvNode(Node):
             return
         _ensure_premasked(g, y)
         geom = self.geom()
+        # filter / bias gradients are side work (only Adam reads them): own scratch, may run on the side stream
+        g.lib.plan_side(1)
         if self.transposed:
-            g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, g.ws_ptr, g.ws_bytes, g.stream)
+            g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, g.ws2_ptr, g.ws_bytes, g.stream)
         else:
             g.lib.conv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr,
-                               self.b.grad_ptr if self.b is not None else None, g.ws_ptr, g.ws_bytes, g.stream)
+                               self.b.grad_ptr if self.b is not None else None, g.ws2_ptr, g.ws_bytes, g.stream)
+        g.lib.plan_side(0)
         self.w.has_grad = True
         if self.b is not None:
             self.b.has_grad = True
@@ -279,8 +283,10 @@ class LinearNode(Node):
         if not y.grad_written:
             return
         _ensure_premasked(g, y)
+        g.lib.plan_side(1)
         g.lib.fc_wgrad(x.shape[0], x.C, y.C, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
-                       g.ws_ptr, g.ws_bytes, g.stream)
+                       g.ws2_ptr, g.ws_bytes, g.stream)
+        g.lib.plan_side(0)
         self.m.has_grad = self.b.has_grad = True
         if x.requires_grad:
             epi = _epi(mask_of=x)
@@ -427,6 +433,9 @@ class Graph:
         self.stream = None
         self.ws = None
         self.ws_ptr, self.ws_bytes = None, 0
+        self.ws2, self.ws2_ptr = None, None
+        self.side_stream = None
+        self.use_side_stream = os.environ.get('MV3D_SIDE_STREAM', '1') != '0'
         self.plan_fwd = self.plan_bwd = None
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
         self.beta1_power = np.float32(self.beta1)
@@ -517,6 +526,8 @@ class Graph:
         self.ws_bytes = need
         self.ws = torch.empty(max(need // 4, 4), dtype=torch.float32, device=dev)
         self.ws_ptr = self.ws.data_ptr()
+        self.ws2 = torch.empty(max(need // 4, 4), dtype=torch.float32, device=dev)      # scratch of the side-stream work
+        self.ws2_ptr = self.ws2.data_ptr()
 
     # ---------------------------------------------------------------- plans
     def _emit_losses(self, with_grad):
@@ -618,8 +629,16 @@ class Graph:
     def run_forward(self):
         self.lib.plan_run(self.plan_fwd, self._stream_ptr())
 
+    def _side_ptr(self):
+        """Second HIP stream for the filter-gradient kernels of the reverse pass (None on CPU / when disabled)."""
+        if not self.use_side_stream or torch.device(self.device).type != 'cuda':
+            return None
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+        return self.side_stream.cuda_stream
+
     def run_backward(self):
-        self.lib.plan_run(self.plan_bwd, self._stream_ptr())
+        self.lib.plan_run_range2(self.plan_bwd, 0, self.n_launch_bwd, self._stream_ptr(), self._side_ptr())
 
     def allreduce_grads(self):
         if self.world_size > 1:
@@ -643,7 +662,7 @@ class Graph:
         stream = self._stream_ptr()
         begin, works = 0, []
         for end, lo, hi in self.grad_buckets:
-            self.lib.plan_run_range(self.plan_bwd, begin, end, stream)
+            self.lib.plan_run_range2(self.plan_bwd, begin, end, stream, self._side_ptr())
             begin = end
             if hi > lo:
                 works.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.dist_group, async_op=True))
