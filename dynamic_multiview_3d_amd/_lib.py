@@ -62,6 +62,7 @@ STATUS_FUNCS = {
     "mv3d_plan_run": [_vp, _vp],
     "mv3d_plan_run_range": [_vp, _i, _i, _vp],
     "mv3d_plan_run_range2": [_vp, _i, _i, _vp, _vp],
+    "mv3d_plan_run_range_multi": [_vp, _i, _i, _vp, C.POINTER(_vp), _i, _i],
     "mv3d_plan_side": [_i],
     "mv3d_plan_profile": [_vp, _i],
     "mv3d_plan_profile_collect": [_vp],

@@ -19,7 +19,7 @@ struct mv3d_plan {
     bool profile = false;
     std::vector<hipEvent_t> pool;   // 2 events per op per profiled run, collected in bulk
     size_t used = 0;
-    hipEvent_t fork = nullptr, join = nullptr;      // stream dependencies of two-stream runs
+    hipEvent_t fork[MV3D_MAX_SIDE] = {}, join[MV3D_MAX_SIDE] = {};      // stream dependencies of multi-stream runs
 };
 
 namespace mv3d {
@@ -48,8 +48,10 @@ void mv3d_plan_destroy(mv3d_plan* p) {
     if (!p) return;
     if (mv3d::g_rec == p) mv3d::g_rec = nullptr;
     for (hipEvent_t e : p->pool) (void)hipEventDestroy(e);
-    if (p->fork) (void)hipEventDestroy(p->fork);
-    if (p->join) (void)hipEventDestroy(p->join);
+    for (int k = 0; k < MV3D_MAX_SIDE; ++k) {
+        if (p->fork[k]) (void)hipEventDestroy(p->fork[k]);
+        if (p->join[k]) (void)hipEventDestroy(p->join[k]);
+    }
     delete p;
 }
 int mv3d_plan_begin(mv3d_plan* p) {
@@ -64,7 +66,8 @@ int mv3d_plan_begin(mv3d_plan* p) {
 // Launches recorded after mv3d_plan_side(1) (until mv3d_plan_side(0)) are tagged as side work: they depend on
 // everything recorded before them, and nothing recorded later in the same plan range depends on them.
 int mv3d_plan_side(int side) {
-    mv3d::g_side = side ? 1 : 0;
+    if (side < 0 || side > MV3D_MAX_SIDE) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_side: side %d not in [0, %d]", side, MV3D_MAX_SIDE);
+    mv3d::g_side = side;
     return MV3D_OK;
 }
 int mv3d_plan_end(void) {
@@ -78,41 +81,51 @@ int mv3d_plan_size(const mv3d_plan* p) { return p ? (int)p->ops.size() : 0; }
 // consecutive ranges (data-parallel training interleaves bucket all-reduces): the event pool slot of
 // op i is (pass base + 2i), and the pass is closed when a range ends at the last op.
 int mv3d_plan_run_range(mv3d_plan* p, int begin, int end, void* stream) {
-    return mv3d_plan_run_range2(p, begin, end, stream, nullptr);
+    return mv3d_plan_run_range_multi(p, begin, end, stream, nullptr, 0, 0);
 }
 
-// Two-stream form: side-tagged launches go to `side_stream` behind an event on `stream` (fork at every
-// main -> side transition), `stream` waits for the side stream once at the end of the range (join).
 int mv3d_plan_run_range2(mv3d_plan* p, int begin, int end, void* stream, void* side_stream) {
+    void* sides[1] = {side_stream};
+    return mv3d_plan_run_range_multi(p, begin, end, stream, sides, side_stream ? 1 : 0, 0);
+}
+
+// Multi-stream form: launches tagged side k (1..nside) go to side_streams[(k-1) % nside] behind an event on `stream`
+// (fork whenever a side's run of launches begins), `stream` waits for every used side stream at the end of the range.
+int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, void* const* side_streams, int nside, int flags) {
     if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: null plan");
     if (mv3d::g_rec) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: cannot run while recording");
     const int n = (int)p->ops.size();
     if (begin < 0 || end > n || begin > end) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range: bad range [%d, %d) of %d", begin, end, n);
+    if (nside < 0 || nside > MV3D_MAX_SIDE || (nside > 0 && !side_streams)) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_range_multi: bad side stream list");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipStream_t s2 = reinterpret_cast<hipStream_t>(side_stream);
-    const bool two = side_stream != nullptr && s2 != s;
-    if (two && !p->fork) {
-        if (hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&p->join, hipEventDisableTiming) != hipSuccess)
-            return mv3d::fail(MV3D_E_HIP, "mv3d_plan_run_range2: hipEventCreate failed");
-    }
+    for (int k = 0; k < nside; ++k)
+        if (!p->fork[k]) {
+            if (hipEventCreateWithFlags(&p->fork[k], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&p->join[k], hipEventDisableTiming) != hipSuccess)
+                return mv3d::fail(MV3D_E_HIP, "mv3d_plan_run_range_multi: hipEventCreate failed");
+        }
     int prev_side = 0;
-    bool side_used = false;
+    bool used[MV3D_MAX_SIDE] = {};
     auto stream_of = [&](int i) -> hipStream_t {
-        const int sd = two ? p->ops[i].side : 0;
-        if (sd == 1 && prev_side == 0) {                     // fork: side work sees everything issued so far
-            (void)hipEventRecord(p->fork, s);
-            (void)hipStreamWaitEvent(s2, p->fork, 0);
-            side_used = true;
+        const int tag = p->ops[i].side;
+        const int sd = (nside > 0 && tag > 0) ? 1 + (tag - 1) % nside : 0;
+        hipStream_t so = sd ? reinterpret_cast<hipStream_t>(side_streams[sd - 1]) : s;
+        if (sd && so == s) { prev_side = 0; return s; }
+        if (sd && sd != prev_side) {                         // fork: side work sees everything issued on the main stream so far
+            (void)hipEventRecord(p->fork[sd - 1], s);
+            (void)hipStreamWaitEvent(so, p->fork[sd - 1], 0);
+            used[sd - 1] = true;
         }
         prev_side = sd;
-        return sd ? s2 : s;
+        return so;
     };
     auto join = [&]() {
-        if (side_used) {
-            (void)hipEventRecord(p->join, s2);
-            (void)hipStreamWaitEvent(s, p->join, 0);
-        }
+        if (flags & MV3D_RUN_NO_JOIN) return;
+        for (int k = 0; k < nside; ++k)
+            if (used[k]) {
+                (void)hipEventRecord(p->join[k], reinterpret_cast<hipStream_t>(side_streams[k]));
+                (void)hipStreamWaitEvent(s, p->join[k], 0);
+            }
     };
     if (!p->profile) {
         for (int i = begin; i < end; ++i) {

@@ -246,13 +246,13 @@ class ConvNode(Node):
         _ensure_premasked(g, y)
         geom = self.geom()
         # filter / bias gradients are side work (only Adam reads them): own scratch, may run on the side stream
-        g.lib.plan_side(1)
+        ws_side = g.begin_side()
         if self.transposed:
-            g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, g.ws2_ptr, g.ws_bytes, g.stream)
+            g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, ws_side, g.ws_bytes, g.stream)
         else:
             g.lib.conv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr,
-                               self.b.grad_ptr if self.b is not None else None, g.ws2_ptr, g.ws_bytes, g.stream)
-        g.lib.plan_side(0)
+                               self.b.grad_ptr if self.b is not None else None, ws_side, g.ws_bytes, g.stream)
+        g.end_side()
         self.w.has_grad = True
         if self.b is not None:
             self.b.has_grad = True
@@ -283,10 +283,10 @@ class LinearNode(Node):
         if not y.grad_written:
             return
         _ensure_premasked(g, y)
-        g.lib.plan_side(1)
+        ws_side = g.begin_side()
         g.lib.fc_wgrad(x.shape[0], x.C, y.C, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
-                       g.ws2_ptr, g.ws_bytes, g.stream)
-        g.lib.plan_side(0)
+                       ws_side, g.ws_bytes, g.stream)
+        g.end_side()
         self.m.has_grad = self.b.has_grad = True
         if x.requires_grad:
             epi = _epi(mask_of=x)
@@ -433,9 +433,13 @@ class Graph:
         self.stream = None
         self.ws = None
         self.ws_ptr, self.ws_bytes = None, 0
-        self.ws2, self.ws2_ptr = None, None
-        self.side_stream = None
-        self.use_side_stream = os.environ.get('MV3D_SIDE_STREAM', '1') != '0'
+        self.n_side = max(0, min(4, int(os.environ.get('MV3D_SIDE_STREAMS', '1'))))      # 0: single-stream reverse pass
+        self.ws_side = []
+        self.side_streams = None
+        self._side_rr = 0
+        self.adam_stream = None
+        self.adam_timing = None         # list of (start, end) events per optimiser launch when a bench wants them
+        self.overlap_adam = os.environ.get('MV3D_OVERLAP_ADAM', '1') != '0'
         self.plan_fwd = self.plan_bwd = None
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
         self.beta1_power = np.float32(self.beta1)
@@ -526,8 +530,8 @@ class Graph:
         self.ws_bytes = need
         self.ws = torch.empty(max(need // 4, 4), dtype=torch.float32, device=dev)
         self.ws_ptr = self.ws.data_ptr()
-        self.ws2 = torch.empty(max(need // 4, 4), dtype=torch.float32, device=dev)      # scratch of the side-stream work
-        self.ws2_ptr = self.ws2.data_ptr()
+        # one scratch buffer per side-work class (classes may run concurrently)
+        self.ws_side = [torch.empty(max(need // 4, 4), dtype=torch.float32, device=dev) for _ in range(self.n_side)]
 
     # ---------------------------------------------------------------- plans
     def _emit_losses(self, with_grad):
@@ -629,28 +633,82 @@ class Graph:
     def run_forward(self):
         self.lib.plan_run(self.plan_fwd, self._stream_ptr())
 
-    def _side_ptr(self):
-        """Second HIP stream for the filter-gradient kernels of the reverse pass (None on CPU / when disabled)."""
-        if not self.use_side_stream or torch.device(self.device).type != 'cuda':
-            return None
-        if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=self.device)
-        return self.side_stream.cuda_stream
+    def begin_side(self):
+        """Tag the calls recorded until end_side() as side work (round-robin over the side classes); returns the
+        scratch pointer reserved for that class."""
+        if self.n_side == 0:
+            return self.ws_ptr
+        k = self._side_rr % self.n_side
+        self._side_rr += 1
+        self.lib.plan_side(k + 1)
+        return self.ws_side[k].data_ptr()
+
+    def end_side(self):
+        if self.n_side:
+            self.lib.plan_side(0)
+
+    def _side_ptrs(self):
+        """HIP streams for the filter-gradient kernels of the reverse pass (empty on CPU / when disabled)."""
+        if self.n_side == 0 or torch.device(self.device).type != 'cuda':
+            return None, 0
+        if self.side_streams is None:
+            self.side_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_side)]
+            self._side_arr = (C.c_void_p * self.n_side)(*[st.cuda_stream for st in self.side_streams])
+        return self._side_arr, self.n_side
 
     def run_backward(self):
-        self.lib.plan_run_range2(self.plan_bwd, 0, self.n_launch_bwd, self._stream_ptr(), self._side_ptr())
+        sides, ns = self._side_ptrs()
+        self.lib.plan_run_range_multi(self.plan_bwd, 0, self.n_launch_bwd, self._stream_ptr(), sides, ns, 0)
 
     def allreduce_grads(self):
         if self.world_size > 1:
             from .parallel import allreduce_sum_
             allreduce_sum_(self.grads, self.dist_group)
 
-    def apply_adam(self):
-        self.lib.adam_step(self.flat_size, self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
-                           self.adam_v.data_ptr(), float(self.lr), self.beta1, self.beta2, self.eps,
-                           float(self.beta1_power), float(self.beta2_power), 1.0 / self.world_size, self._stream_ptr())
+    def _adam_range(self, lo, hi, stream):
+        off = lo * 4
+        self.lib.adam_step(hi - lo, self.params.data_ptr() + off, self.grads.data_ptr() + off, self.adam_m.data_ptr() + off,
+                           self.adam_v.data_ptr() + off, float(self.lr), self.beta1, self.beta2, self.eps,
+                           float(self.beta1_power), float(self.beta2_power), 1.0 / self.world_size, stream)
+
+    def _adam_advance(self):
         self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
+
+    def apply_adam(self):
+        self._adam_range(0, self.flat_size, self._stream_ptr())
+        self._adam_advance()
+
+    def run_backward_with_adam(self):
+        """Single-GPU reverse pass with the optimiser folded in: the backward plan is issued bucket by bucket
+        (the same >= 64 MB suffix buckets the data-parallel path all-reduces); as soon as a bucket's gradients are
+        final -- its filter-gradient kernels sit on the side streams -- Adam for that slice of the flat buffers
+        starts on its own stream while the main stream continues with the data gradients of the layers below.
+        Adam is pure HBM streaming (28 B per parameter), the convolution kernels it overlaps are MFMA / latency bound."""
+        main = torch.cuda.current_stream(self.device)
+        sides, ns = self._side_ptrs()
+        if self.adam_stream is None:
+            self.adam_stream = torch.cuda.Stream(device=self.device)
+        begin = 0
+        for end, lo, hi in self.grad_buckets:
+            self.lib.plan_run_range_multi(self.plan_bwd, begin, end, main.cuda_stream, sides, ns, 1)      # no join
+            begin = end
+            if hi > lo:
+                # the slice's gradients come from side-stream kernels; its weights were last read by main-stream kernels
+                self.adam_stream.wait_stream(main)
+                for st in (self.side_streams or []):
+                    self.adam_stream.wait_stream(st)
+                if self.adam_timing is not None:      # bench: HIP events around the optimiser launches, on their stream
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.adam_stream)
+                self._adam_range(lo, hi, self.adam_stream.cuda_stream)
+                if self.adam_timing is not None:
+                    e1.record(self.adam_stream)
+                    self.adam_timing.append((e0, e1))
+        main.wait_stream(self.adam_stream)
+        for st in (self.side_streams or []):
+            main.wait_stream(st)
+        self._adam_advance()
 
     def run_backward_overlapped(self):
         """Data-parallel reverse pass: the recorded backward sequence is issued in segments; after each
@@ -660,9 +718,10 @@ class Graph:
         ~60 % of the backward FLOPs -- overlaps the encoder's backward kernels."""
         import torch.distributed as dist
         stream = self._stream_ptr()
+        sides, ns = self._side_ptrs()
         begin, works = 0, []
         for end, lo, hi in self.grad_buckets:
-            self.lib.plan_run_range2(self.plan_bwd, begin, end, stream, self._side_ptr())
+            self.lib.plan_run_range_multi(self.plan_bwd, begin, end, stream, sides, ns, 0)
             begin = end
             if hi > lo:
                 works.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.dist_group, async_op=True))
@@ -674,9 +733,12 @@ class Graph:
         self.run_forward()
         if self.world_size > 1:
             self.run_backward_overlapped()
+            self.apply_adam()
+        elif self.overlap_adam and torch.device(self.device).type == 'cuda':
+            self.run_backward_with_adam()
         else:
             self.run_backward()
-        self.apply_adam()
+            self.apply_adam()
         return self.loss_buf[0]
 
     # ---------------------------------------------------------------- variables I/O

@@ -174,14 +174,18 @@ int mv3d_plan_run(mv3d_plan* p, void* stream);
 /* launches ops [begin, end) only: lets the host interleave other stream work (bucket all-reduces of
  * the data-parallel path) between segments of the recorded backward sequence */
 int mv3d_plan_run_range(mv3d_plan* p, int begin, int end, void* stream);
-/* Two-stream runs.  Calls recorded between mv3d_plan_side(1) and mv3d_plan_side(0) are "side work": they depend on
+/* Two-stream runs.  Calls recorded between mv3d_plan_side(k > 0) and mv3d_plan_side(0) are "side work": they depend on
  * everything recorded before them and nothing recorded after them in the plan depends on them (the filter / bias
  * gradients of the reverse pass: only the optimiser reads them).  mv3d_plan_run_range2 issues side work on
  * `side_stream` behind an event on `stream` and makes `stream` wait for it at the end of the range, so the filter
  * gradients of a layer run concurrently with the data gradients of the layers below it.  Side work must not share
  * scratch memory with main work.  side_stream == NULL: same as mv3d_plan_run_range. */
-int mv3d_plan_side(int side);
+#define MV3D_MAX_SIDE 4
+int mv3d_plan_side(int side);                  /* 0 = main, 1..MV3D_MAX_SIDE = side work class */
 int mv3d_plan_run_range2(mv3d_plan* p, int begin, int end, void* stream, void* side_stream);
+/* side class k runs on side_streams[(k-1) % nside]; classes on different streams must not share scratch either */
+#define MV3D_RUN_NO_JOIN 1      /* the caller orders `stream` behind the side streams itself */
+int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, void* const* side_streams, int nside, int flags);
 /* Per-launch timing for the roofline report: with profiling enabled, mv3d_plan_run brackets every
  * recorded launch with hipEventRecord on the launch stream (no host synchronisation);
  * mv3d_plan_profile_collect() synchronises once and folds all runs into per-op totals.

@@ -84,7 +84,7 @@ def _overlap_worker(rank, world, port, q):
     segments = []
 
     class FakeLib:
-        def plan_run_range2(self, plan, begin, end, stream, side_stream):
+        def plan_run_range_multi(self, plan, begin, end, stream, side_streams, nside, flags):
             segments.append((begin, end))
     real_lib, g.lib = g.lib, FakeLib()
     g._stream_ptr = lambda: None
