@@ -526,6 +526,183 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
+
+// ---- filter gradient when the image side has 1..4 channels (e0: rgb -> 32, the 2/3/1-channel heads) --------------
+// df[tap][c][k] = sum_pixels img[pixel*s + tap][c] * feat[pixel][k] is a (taps*C <= 100) x (K <= 32 per workgroup column)
+// matrix accumulated over N*Ho*Wo ~ 262k pixels: 1 GFLOP over 46 MB, i.e. a streaming problem.  A workgroup walks a slab
+// of output-row blocks; per block the image rows and the feature rows are staged in LDS (fp32, exact); thread (kq, rg)
+// owns filters 4kq..4kq+3 of up to four (tap, c) rows and does rank-1 updates from a 16-byte feature read and one
+// (broadcast) image read per row.  Per-slab partials + reduce_slabs_kernel, like every other filter gradient.
+struct ThinFgParams {
+    const float* img; const float* feat;
+    float* out; float* bias_out;
+    int N, H, W, C, img_ld;
+    int Ho, Wo, K, feat_ld;
+    int kh, kw, sh, sw, pt, pl;
+    int TR;                       // output rows per staged block
+    int IR, IW;                   // staged image rows / columns: (TR-1)*sh + kh, (Wo-1)*sw + kw
+    int blocks_per_img, blocks_total, blocks_per_slab;
+    int nrows;                    // taps * C
+};
+
+typedef float tf2 __attribute__((ext_vector_type(2)));
+
+// lane = (kq = lane & 3: filters 8kq..8kq+7 of the workgroup's 32, rgrp = lane >> 2: rows rgrp + 16j, j < NJ): a wave
+// covers the whole (taps*C) x 32 block, 8*NJ accumulators per lane, 8*NJ FMAs per (2 + NJ) LDS reads; the four waves
+// take every fourth pixel of a staged block and their partials are combined through LDS at the end (fixed order).
+template <int NJ>
+__global__ __launch_bounds__(256) void thin_filtgrad_kernel(const ThinFgParams p) {
+    extern __shared__ __attribute__((aligned(16))) float tfs[];
+    float* img_s = tfs;                                   // [IR][IW][C]
+    float* feat_s = tfs + ((p.IR * p.IW * p.C + 3) & ~3); // [TR][Wo][32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int kq = lane & 3, rgrp = lane >> 2;
+    const int k0 = blockIdx.x * 32;
+    const int slab = blockIdx.y;
+    int roff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int row = rgrp + 16 * j;
+        const int rr = row < p.nrows ? row : 0;
+        const int tap = rr / p.C, c = rr - tap * p.C;
+        roff[j] = ((tap / p.kw) * p.IW + (tap % p.kw)) * p.C + c;
+    }
+    tf2 acc[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = tf2{0.f, 0.f};
+    tf2 bsum[4] = {tf2{0.f, 0.f}, tf2{0.f, 0.f}, tf2{0.f, 0.f}, tf2{0.f, 0.f}};
+    const int b_begin = slab * p.blocks_per_slab, b_end = min(b_begin + p.blocks_per_slab, p.blocks_total);
+    const int n_img = p.IR * p.IW * p.C;
+    const int row_elems = p.IW * p.C;
+    const int npx = p.TR * p.Wo;
+    for (int blk = b_begin; blk < b_end; ++blk) {
+        const int n = blk / p.blocks_per_img, oh0 = (blk - n * p.blocks_per_img) * p.TR;
+        const int ih0 = oh0 * p.sh - p.pt, iw0 = -p.pl;
+        if (blk > b_begin) __syncthreads();
+        // image rows: one staged row per wave pass, lanes along the row (contiguous in global memory when img_ld == C)
+        for (int r = wave; r < p.IR; r += 4) {
+            const int ih = ih0 + r;
+            const bool row_ok = (unsigned)ih < (unsigned)p.H;
+            const float* src = p.img + (int64_t)((n * p.H + (row_ok ? ih : 0)) * p.W) * p.img_ld;
+            for (int e = lane; e < row_elems; e += 64) {
+                const int col = e / p.C, c = e - col * p.C;
+                const int iw = iw0 + col;
+                float v = 0.f;
+                if (row_ok && (unsigned)iw < (unsigned)p.W) v = src[(int64_t)iw * p.img_ld + c];
+                img_s[r * row_elems + e] = v;
+            }
+        }
+        // feature rows: TR x Wo x 32 floats as float4
+        for (int i = tid; i < npx * 8; i += 256) {
+            const int c4 = i & 7, px = i >> 3;
+            const int r = px / p.Wo, ow = px - r * p.Wo;
+            const int oh = oh0 + r, kk = k0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oh < p.Ho && kk < p.K) v = *reinterpret_cast<const float4*>(p.feat + (int64_t)((n * p.Ho + oh) * p.Wo + ow) * p.feat_ld + kk);
+            *reinterpret_cast<float4*>(feat_s + (size_t)px * 32 + c4 * 4) = v;
+        }
+        __syncthreads();
+        for (int r = 0; r < p.TR; ++r) {
+            const float* frow = feat_s + (size_t)r * p.Wo * 32 + kq * 8;
+            const float* irow = img_s + (size_t)(r * p.sh) * row_elems;
+#pragma unroll 4
+            for (int ow = wave; ow < p.Wo; ow += 4) {
+                const float4 f0 = *reinterpret_cast<const float4*>(frow + ow * 32);
+                const float4 f1 = *reinterpret_cast<const float4*>(frow + ow * 32 + 4);
+                const tf2 fv[4] = {tf2{f0.x, f0.y}, tf2{f0.z, f0.w}, tf2{f1.x, f1.y}, tf2{f1.z, f1.w}};
+                const float* ip = irow + ow * p.sw * p.C;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float a = ip[roff[j]];
+                    const tf2 av = tf2{a, a};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] = __builtin_elementwise_fma(av, fv[e], acc[j][e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[e] += fv[e];
+            }
+        }
+    }
+    // combine the four waves' partials through LDS (wave 0 adds waves 1..3 in order), then store
+    __syncthreads();
+    float* xch = tfs;                                      // [3][NJ*8 + 8][64]
+    constexpr int NV = NJ * 8 + 8;
+    if (wave > 0) {
+        float* d = xch + (size_t)(wave - 1) * NV * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d[((j * 4 + e) * 2) * 64] = acc[j][e].x; d[((j * 4 + e) * 2 + 1) * 64] = acc[j][e].y; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { d[(NJ * 8 + e * 2) * 64] = bsum[e].x; d[(NJ * 8 + e * 2 + 1) * 64] = bsum[e].y; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < 3; ++w) {
+            const float* d = xch + (size_t)w * NV * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[j][e].x += d[((j * 4 + e) * 2) * 64]; acc[j][e].y += d[((j * 4 + e) * 2 + 1) * 64]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bsum[e].x += d[(NJ * 8 + e * 2) * 64]; bsum[e].y += d[(NJ * 8 + e * 2 + 1) * 64]; }
+        }
+        const int64_t fcount = (int64_t)p.kh * p.kw * p.C * p.K;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = rgrp + 16 * j;                // = tap * C + c
+            if (row >= p.nrows) continue;
+            float* o = p.out + (int64_t)slab * fcount + (int64_t)row * p.K + k0 + kq * 8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (k0 + kq * 8 + 2 * e < p.K) o[2 * e] = acc[j][e].x;
+                if (k0 + kq * 8 + 2 * e + 1 < p.K) o[2 * e + 1] = acc[j][e].y;
+            }
+        }
+        if (p.bias_out && rgrp == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (k0 + kq * 8 + 2 * e < p.K) p.bias_out[(int64_t)slab * p.K + k0 + kq * 8 + 2 * e] = bsum[e].x;
+                if (k0 + kq * 8 + 2 * e + 1 < p.K) p.bias_out[(int64_t)slab * p.K + k0 + kq * 8 + 2 * e + 1] = bsum[e].y;
+            }
+        }
+    }
+}
+
+static bool thin_filtgrad_plan(const mv3d_conv_geom* g, ThinFgParams& p, int* nslab_out, size_t* lds_out) {
+    if (disabled_paths() & 16384) return false;
+    if (g->C > 4 || g->kh * g->kw * g->C > 112 || g->K % 4 != 0 || g->feat_ld % 4 != 0 || g->Wo < 8) return false;
+    p = ThinFgParams{};
+    p.N = g->N; p.H = g->H; p.W = g->W; p.C = g->C; p.img_ld = g->img_ld;
+    p.Ho = g->Ho; p.Wo = g->Wo; p.K = g->K; p.feat_ld = g->feat_ld;
+    p.kh = g->kh; p.kw = g->kw; p.sh = g->sh; p.sw = g->sw;
+    int ho, wo;
+    same_pad(g->H, g->kh, g->sh, &ho, &p.pt);
+    same_pad(g->W, g->kw, g->sw, &wo, &p.pl);
+    p.nrows = g->kh * g->kw * g->C;
+    p.IW = (g->Wo - 1) * g->sw + g->kw;
+    size_t lds = 0;
+    for (int tr = 4; tr >= 1; tr >>= 1) {
+        p.TR = std::min(tr, g->Ho);
+        p.IR = (p.TR - 1) * g->sh + g->kh;
+        lds = (size_t)(((p.IR * p.IW * p.C + 3) & ~3) + p.TR * g->Wo * 32) * sizeof(float);
+        if (lds <= 52 * 1024) break;
+    }
+    if (lds > 64 * 1024) return false;
+    p.blocks_per_img = cdiv(g->Ho, p.TR);
+    p.blocks_total = g->N * p.blocks_per_img;
+    const int kcols = cdiv(g->K, 32);
+    int nslab = std::max(1, std::min(p.blocks_total, 768 / kcols));
+    p.blocks_per_slab = cdiv(p.blocks_total, nslab);
+    nslab = cdiv(p.blocks_total, p.blocks_per_slab);
+    *nslab_out = nslab;
+    *lds_out = lds;
+    return true;
+}
+
 static int dispatch_reduce(void* stream, const float* part, int nslab, int64_t fcount, float* df, const float* bpart, int K, float* db) {
     const int blocks1 = (int)cdiv64(fcount, 16);
     const int blocks2 = (db && bpart) ? cdiv(K, 16) : 0;
@@ -884,6 +1061,10 @@ static void filtgrad_plan(const mv3d_conv_geom* g, FiltgradParams& p, int* nt_ou
 int wgrad_tile_nslab(const mv3d_conv_geom* g);
 
 static size_t filtgrad_ws_bytes(const mv3d_conv_geom* g) {
+    {
+        ThinFgParams tp; int ns; size_t lds;
+        if (thin_filtgrad_plan(g, tp, &ns, &lds)) return (size_t)ns * ((size_t)g->kh * g->kw * g->C * g->K + g->K) * sizeof(float);
+    }
     FiltgradParams p = {};
     int NT, nslab;
     filtgrad_plan(g, p, &NT, &nslab);
@@ -915,6 +1096,27 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
             rc = wgrad_tile_launch_erased(g, img, feat, part, bpart, stream, who, &ns);
             if (rc != MV3D_OK || ns == 1) return rc;
             return dispatch_reduce(stream, part, ns, fcount, dfp, bpart, K, dbp);
+        }
+    }
+    {   // 1..4 image-side channels: streaming VALU kernel
+        ThinFgParams tp; int ns; size_t lds;
+        if (thin_filtgrad_plan(g, tp, &ns, &lds) && (reinterpret_cast<uintptr_t>(feat) & 15) == 0) {
+            const size_t need = (size_t)ns * (fcount + K) * sizeof(float);
+            if (!ws || ws_bytes < need) return fail(MV3D_E_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
+            tp.img = (const float*)img; tp.feat = (const float*)feat;
+            tp.out = (float*)ws;
+            tp.bias_out = db ? (float*)ws + (int64_t)ns * fcount : nullptr;
+            dim3 grid(cdiv(g->K, 32), ns);
+            const int nj = cdiv(tp.nrows, 16);
+            rc = dispatch(stream, OpInfo{"thin_filtgrad", conv_flops(g), conv_bytes(g)}, [=](hipStream_t s) {
+                if (nj <= 2) thin_filtgrad_kernel<2><<<grid, 256, lds, s>>>(tp);
+                else if (nj <= 4) thin_filtgrad_kernel<4><<<grid, 256, lds, s>>>(tp);
+                else if (nj <= 5) thin_filtgrad_kernel<5><<<grid, 256, lds, s>>>(tp);
+                else thin_filtgrad_kernel<7><<<grid, 256, lds, s>>>(tp);
+                return launched(who);
+            });
+            if (rc != MV3D_OK) return rc;
+            return dispatch_reduce(stream, tp.out, ns, fcount, dfp, tp.bias_out, K, dbp);
         }
     }
     FiltgradParams p = {};

@@ -531,7 +531,9 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     p.ntiles_total = g->N * p.tiles_h * p.tiles_w;
     // one workgroup per CU in total (operands are prefetched inside the workgroup)
     const int blocks_xy = p.ctiles * kgroups;
-    int nslab = std::max(1, 256 / blocks_xy);
+    static int wg_cus = -1;
+    if (wg_cus < 0) { const char* e = getenv("MV3D_WG_CUS"); wg_cus = e ? atoi(e) : 256; }
+    int nslab = std::max(1, wg_cus / blocks_xy);
     if (nslab > p.ntiles_total) nslab = p.ntiles_total;
     p.tiles_per_slab = cdiv(p.ntiles_total, nslab);
     nslab = cdiv(p.ntiles_total, p.tiles_per_slab);

@@ -246,7 +246,9 @@ class ConvNode(Node):
         _ensure_premasked(g, y)
         geom = self.geom()
         # filter / bias gradients are side work (only Adam reads them): own scratch, may run on the side stream
-        ws_side = g.begin_side()
+        kh, kw = self.k[0], self.k[1]
+        us = 12.0 + 2.0 * geom.N * geom.Ho * geom.Wo * kh * kw * geom.C * geom.K / 120e6      # rough kernel time, microseconds
+        ws_side = g.begin_side(us + 10.0, us if x.requires_grad else 0.0)
         if self.transposed:
             g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, ws_side, g.ws_bytes, g.stream)
         else:
@@ -283,7 +285,7 @@ class LinearNode(Node):
         if not y.grad_written:
             return
         _ensure_premasked(g, y)
-        ws_side = g.begin_side()
+        ws_side = g.begin_side(25.0, 32.0 if x.requires_grad else 0.0)
         g.lib.fc_wgrad(x.shape[0], x.C, y.C, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
                        ws_side, g.ws_bytes, g.stream)
         g.end_side()
@@ -437,6 +439,8 @@ class Graph:
         self.ws_side = []
         self.side_streams = None
         self._side_rr = 0
+        self._clk_main = self._clk_side = 0.0
+        self.balance_streams = os.environ.get('MV3D_BALANCE', '0') != '0'     # measured: level clocks do not pay (concurrent kernels share the CUs)
         self.adam_stream = None
         self.adam_timing = None         # list of (start, end) events per optimiser launch when a bench wants them
         self.overlap_adam = os.environ.get('MV3D_OVERLAP_ADAM', '1') != '0'
@@ -573,8 +577,12 @@ class Graph:
             order = list(self.variables.values())
             suffix = len(order)         # variables[suffix:] are complete
             cut_hi = self.flat_size
+            gate = 0
+            self._clk_main = self._clk_side = 0.0
             for n in reversed(self.nodes):
                 n.backward(self)
+                if isinstance(n, LinearNode):
+                    gate = lib.plan_size(self.plan_bwd)
                 for v in (getattr(n, 'w', None), getattr(n, 'b', None), getattr(n, 'm', None)):
                     if isinstance(v, Variable):
                         done.add(v.name)
@@ -594,6 +602,20 @@ class Graph:
         else:
             end, lo, hi = self.grad_buckets[-1]
             self.grad_buckets[-1] = (nbwd, lo, hi)
+        # Extra (empty) segment boundary: the optimiser launches of the early (fc) buckets are held back until the main
+        # stream is past the fc layers and the small-spatial convolutions -- kernels that stream HBM or wait on it like
+        # Adam does and slow down 3-10x next to it -- and overlap the encoder's large MFMA-bound layers instead
+        # (measured best at ~0.65 of the backward launch list; 'fc' = right behind the last fully-connected layer).
+        mode = os.environ.get('MV3D_ADAM_GATE', '0.65')      # 'fc', 'none' or a fraction of the backward launch list
+        if mode == 'none':
+            gate = 0
+        elif mode != 'fc':
+            gate = int(float(mode) * nbwd)
+        self.adam_gate = gate if 0 < gate < nbwd else 0
+        if self.adam_gate and all(b[0] != self.adam_gate for b in self.grad_buckets):
+            i = next(j for j, b in enumerate(self.grad_buckets) if b[0] > self.adam_gate)
+            hi = self.grad_buckets[i][2]
+            self.grad_buckets.insert(i, (self.adam_gate, hi, hi))
         # Adam runs over the prefix of the flat buffer that holds variables with a gradient path;
         # variables without one (highdim_angle.py:8-9) keep zero gradients and are never touched.
         self.n_launch_fwd = lib.plan_size(self.plan_fwd)
@@ -633,11 +655,18 @@ class Graph:
     def run_forward(self):
         self.lib.plan_run(self.plan_fwd, self._stream_ptr())
 
-    def begin_side(self):
+    def begin_side(self, cost_side=0.0, cost_main=0.0):
         """Tag the calls recorded until end_side() as side work (round-robin over the side classes); returns the
-        scratch pointer reserved for that class."""
-        if self.n_side == 0:
+        scratch pointer reserved for that class.  cost_side / cost_main: estimated microseconds of the side work
+        (a layer's filter gradient) and of the main-stream work recorded next (its data gradient): the side chain
+        does strictly more work than the main chain, so a greedy list schedule keeps the two clocks level by
+        leaving a filter gradient on the main stream whenever the side stream is more than one kernel ahead."""
+        fork = self._clk_main
+        if self.n_side == 0 or (self.balance_streams and self._clk_side > self._clk_main + cost_main):
+            self._clk_main += cost_side + cost_main
             return self.ws_ptr
+        self._clk_side = max(self._clk_side, fork) + cost_side
+        self._clk_main += cost_main
         k = self._side_rr % self.n_side
         self._side_rr += 1
         self.lib.plan_side(k + 1)
@@ -689,22 +718,27 @@ class Graph:
         sides, ns = self._side_ptrs()
         if self.adam_stream is None:
             self.adam_stream = torch.cuda.Stream(device=self.device)
-        begin = 0
+        begin, pending = 0, []
         for end, lo, hi in self.grad_buckets:
             self.lib.plan_run_range_multi(self.plan_bwd, begin, end, main.cuda_stream, sides, ns, 1)      # no join
             begin = end
             if hi > lo:
-                # the slice's gradients come from side-stream kernels; its weights were last read by main-stream kernels
-                self.adam_stream.wait_stream(main)
-                for st in (self.side_streams or []):
-                    self.adam_stream.wait_stream(st)
+                pending.append((lo, hi))
+            if end < self.adam_gate or not pending:
+                continue
+            # the slices' gradients come from side-stream kernels; their weights were last read by main-stream kernels
+            self.adam_stream.wait_stream(main)
+            for st in (self.side_streams or []):
+                self.adam_stream.wait_stream(st)
+            for plo, phi in pending:
                 if self.adam_timing is not None:      # bench: HIP events around the optimiser launches, on their stream
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.adam_stream)
-                self._adam_range(lo, hi, self.adam_stream.cuda_stream)
+                self._adam_range(plo, phi, self.adam_stream.cuda_stream)
                 if self.adam_timing is not None:
                     e1.record(self.adam_stream)
                     self.adam_timing.append((e0, e1))
+            pending = []
         main.wait_stream(self.adam_stream)
         for st in (self.side_streams or []):
             main.wait_stream(st)

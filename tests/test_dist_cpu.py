@@ -120,7 +120,8 @@ def test_overlapped_bucket_allreduce_two_ranks():
         assert all(a[1] == b[0] for a, b in zip(segments, segments[1:]))
         assert buckets[0][2] == flat and buckets[-1][1] == 0
         assert all(a[1] == b[2] for a, b in zip(buckets, buckets[1:]))          # contiguous, descending
-        assert len(buckets) >= 4 and all((hi - lo) * 4 >= 60e6 for _, lo, hi in buckets[:-1])
+        full = [b for b in buckets if b[2] > b[1]]          # an empty bucket marks the end of the fc layers (Adam gate)
+        assert len(full) >= 4 and all((hi - lo) * 4 >= 60e6 for _, lo, hi in full[:-1])
 
 
 def test_shard_batch():
