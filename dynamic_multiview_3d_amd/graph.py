@@ -744,7 +744,7 @@ class Graph:
             main.wait_stream(st)
         self._adam_advance()
 
-    def run_backward_overlapped(self):
+    def run_backward_overlapped(self, with_adam=False):
         """Data-parallel reverse pass: the recorded backward sequence is issued in segments; after each
         segment the gradients it completed (a contiguous suffix range of the flat buffer, >= 64 MB) are
         SUM-all-reduced asynchronously (RCCL runs on the process group's own stream behind an event on
@@ -758,16 +758,24 @@ class Graph:
             self.lib.plan_run_range_multi(self.plan_bwd, begin, end, stream, sides, ns, 0)
             begin = end
             if hi > lo:
-                works.append(dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.dist_group, async_op=True))
-        for w in works:
-            w.wait()                    # stream-level wait: Adam is ordered behind the collectives
+                works.append((dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.dist_group, async_op=True), lo, hi))
+        if not with_adam:
+            for w, _, _ in works:
+                w.wait()                # stream-level wait: Adam is ordered behind the collectives
+            return
+        # Adam bucket by bucket: the slice whose all-reduce has finished is updated while the later (smaller, but
+        # later-started) collectives are still on the links -- the optimiser's 1.95 GB of HBM traffic hides under
+        # whatever part of the exchange the reverse pass could not cover
+        for w, lo, hi in works:
+            w.wait()
+            self._adam_range(lo, hi, self._stream_ptr())
+        self._adam_advance()
 
     def train_step(self):
         """forward + loss + reverse pass + (all-reduce) + Adam; returns the device loss scalar."""
         self.run_forward()
         if self.world_size > 1:
-            self.run_backward_overlapped()
-            self.apply_adam()
+            self.run_backward_overlapped(with_adam=True)
         elif self.overlap_adam and torch.device(self.device).type == 'cuda':
             self.run_backward_with_adam()
         else:
