@@ -15,6 +15,19 @@ import json
 import sys
 
 LABEL = {
+    # split-bf16 kernels (round-1 'd' profiles)
+    'bconvu_kernel<25, 5, 2, 1, 4>': 'bconv<1ph,256px,N32>',
+    'bconvu_kernel<25, 5, 1, 1, 2>': 'bconv<1ph,64px,N32>',
+    'bconv_kernel<4, 1, 1, 4>': 'bconv<4ph,128px,N32>',
+    'wgrad_b3_kernel<7, 1, 4>': 'wgrad_b3<5x5,K32>',
+    'wgrad_b3_kernel<7, 1, 8>': 'wgrad_b3<5x5,K32>/stride2',
+    'wgrad_b3_kernel<7, 2, 4>': 'wgrad_b3<5x5,K64>',
+    'wgrad_b3_kernel<7, 2, 8>': 'wgrad_b3<5x5,K64>/stride2',
+    'fc_stream_b3_kernel<false, 2>': 'fc_stream_b3<fwd>',
+    'fc_stream_b3_kernel<true, 2>': 'fc_stream_b3<dgrad>',
+    'mv3d::fc_wgrad_b3_kernel': 'fc_wgrad_b3',
+    'mv3d::bconv_split_all_kernel': 'bconv_split_all',
+    # exact-fp32 kernels (round-1 'b' / 'c' profiles, MV3D_DISABLE=4096)
     'hconvp_kernel<25, 1, 1, false, 9, 8, 25, 25, 25>': 'hconvp<5x5,256px,N32,nmajorB>',
     'hconvp_kernel<25, 1, 1, false, 13, 4, 25, 25, 25>': 'hconvp<5x5,128px,N32,nmajorB>',
     'hconvp_kernel<25, 1, 2, false, 13, 4, 25, 25, 25>': 'hconvp<5x5,128px,N64,nmajorB>',
@@ -26,6 +39,7 @@ LABEL = {
     'fc_stream_kernel<false, 2>': 'fc_stream<fwd>',
     'fc_stream_kernel<true, 2>': 'fc_stream<dgrad>',
     'mv3d::fc_wgrad_kernel': 'fc_wgrad',
+    # both
     'mv3d::adam_kernel': 'adam',
     'mv3d::reduce_slabs_kernel': 'reduce_slabs',
     'mv3d::igemm_splitk_epilogue': 'igemm_splitk_epilogue',
