@@ -690,6 +690,7 @@ static int launch_bconv_cfg(const IgemmParams& p, const HconvExtra& x, int nph_f
         if (MT == 1 && NT == 2 && WAVES == 4) return MV3D_BCU(1, 2, 4);
         if (MT == 1 && NT == 1 && WAVES == 4) return MV3D_BCU(1, 1, 4);
         if (MT == 1 && NT == 1 && WAVES == 2) return MV3D_BCU(1, 1, 2);
+        if (MT == 1 && NT == 2 && WAVES == 2) return MV3D_BCU(1, 2, 2);
 #undef MV3D_BCU
     }
     if (nph_fused == 4) {
@@ -701,6 +702,7 @@ static int launch_bconv_cfg(const IgemmParams& p, const HconvExtra& x, int nph_f
         if (MT == 1 && NT == 2 && WAVES == 4) return MV3D_BC(1, 1, 2, 4);
         if (MT == 1 && NT == 1 && WAVES == 4) return MV3D_BC(1, 1, 1, 4);
         if (MT == 1 && NT == 1 && WAVES == 2) return MV3D_BC(1, 1, 1, 2);
+        if (MT == 1 && NT == 2 && WAVES == 2) return MV3D_BC(1, 1, 2, 2);
     }
 #undef MV3D_BC
     return fail(MV3D_E_UNSUPPORTED, "%s: no split-bf16 kernel for nph=%d MT=%d NT=%d waves=%d", who, nph_fused, MT, NT, WAVES);

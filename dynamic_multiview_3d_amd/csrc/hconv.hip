@@ -598,10 +598,10 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
             if (nph == 1) {
                 struct Cand { int pix, MT, NT, WAVES; const char* name; };
                 const int n2 = p.Cc > 32 ? 2 : 1;
-                const Cand ladder[5] = {{256, 2, n2, 4, n2 == 2 ? "bconv<1ph,256px,N64>" : "bconv<1ph,256px,N32>"}, {256, 2, 1, 4, "bconv<1ph,256px,N32>"},
+                const Cand ladder[6] = {{256, 2, n2, 4, n2 == 2 ? "bconv<1ph,256px,N64>" : "bconv<1ph,256px,N32>"}, {256, 2, 1, 4, "bconv<1ph,256px,N32>"},
                                         {128, 1, n2, 4, n2 == 2 ? "bconv<1ph,128px,N64>" : "bconv<1ph,128px,N32>"}, {128, 1, 1, 4, "bconv<1ph,128px,N32>"},
-                                        {64, 1, 1, 2, "bconv<1ph,64px,N32>"}};
-                for (int c = 0; c < 5; ++c) {
+                                        {64, 1, n2, 2, n2 == 2 ? "bconv<1ph,64px,N64>" : "bconv<1ph,64px,N32>"}, {64, 1, 1, 2, "bconv<1ph,64px,N32>"}};
+                for (int c = 0; c < 6; ++c) {
                     const Cand& cd = ladder[c];
                     static int maxpix = -1;
                     if (maxpix < 0) { const char* e = getenv("MV3D_BC_MAXPIX"); maxpix = e ? atoi(e) : 256; }
