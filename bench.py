@@ -292,6 +292,11 @@ def main():
             for n, k in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
                 rate = ("%7.1f TF/s" % (k['flops'] / k['ms'] / 1e9)) if k['flops'] > 0 else ("%7.0f GB/s" % (k['bytes'] / k['ms'] / 1e6))
                 print("%-34s launches=%3d  ms/step=%8.4f  %s" % (n, k['launches'], k['ms'], rate), file=sys.stderr)
+    # whole step against the roofline the reference's arithmetic implies: algorithmic fp32 FLOPs (3 440 MFLOP per trained
+    # image) over wall time, vs the fp32 MFMA peak -- independent of which matrix-core type carries them
+    out["step_f32_equivalent"] = {"tflops": round(value / world * TRAIN_MFLOP_PER_IMAGE_ALL * 1e6 / 1e12, 2),
+                                  "frac_of_f32_mfma_peak": round(value / world * TRAIN_MFLOP_PER_IMAGE_ALL * 1e6 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "note": "per GPU; includes fc, Adam and every elementwise kernel in the time"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
