@@ -298,8 +298,11 @@ __global__ __launch_bounds__(WAVES * 64) void bconv_kernel(const IgemmParams p, 
 //     right behind the three MFMAs that consumed it, which leaves the rest of the tap to cover the LDS latency;
 //   * tap offsets are compile-time indexed scalars: no scalar loads or waits inside the loop.
 template <int NTAPS, int U, int MT, int NT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void bconvu_kernel(const IgemmParams p, const HconvExtra x, const uint4* __restrict__ Wf, int ntiles) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2))) void bconvu_kernel(const IgemmParams p, const HconvExtra x, const uint4* __restrict__ Wf, int ntiles) {
     static_assert(NTAPS % U == 0, "ring slots must line up across chunks");
+    // look-ahead distance in taps: the whole ring at 32 filters per wave, two taps at 64 (twice the MFMAs per tap and
+    // twice the registers per ring slot; two waves per SIMD need <= 256 registers)
+    constexpr int D = (NT == 1) ? U - 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char halo[];
     constexpr int NTHR = WAVES * 64;
     const int tid = threadIdx.x;
@@ -325,24 +328,21 @@ __global__ __launch_bounds__(WAVES * 64) void bconvu_kernel(const IgemmParams p,
     f32x16 acc[MT][NT];
 
     const int cc_begin = (x.chunks * zks) / x.ksplit, cc_end = (x.chunks * (zks + 1)) / x.ksplit;
-    const int total_seq = (cc_end - cc_begin) * NTAPS;
 
     struct BSet { uint4 b[NT][2][2]; };
     BSet ring[U];
     uint4 a[MT][2][2];
-    const uint4* wf_lane = Wf + (int64_t)(blockIdx.y * NT) * 256 + lane;
-    auto load_b = [&](BSet& f, int seq) {
-        seq = seq < total_seq ? seq : total_seq - 1;
-        const int cq = seq / NTAPS;
-        const int cc = cc_begin + cq;
-        const int t = seq - cq * NTAPS;
-        const uint4* src = wf_lane + ((int64_t)t * x.chunks + cc) * ntiles * 256;
+    // filter fragments of (tap t, chunk cc): wave-uniform base (scalar arithmetic) + lane index
+    const uint4* wf_base = Wf + (int64_t)(blockIdx.y * NT) * 256;
+    const int64_t tap_stride = (int64_t)x.chunks * ntiles * 256, chunk_stride = (int64_t)ntiles * 256;
+    auto load_b = [&](BSet& f, int t, int cc) {
+        const uint4* src = wf_base + t * tap_stride + cc * chunk_stride;
 #pragma unroll
         for (int y = 0; y < NT; ++y)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                f.b[y][s][0] = src[(y * 4 + s * 2) * 64];
-                f.b[y][s][1] = src[(y * 4 + s * 2 + 1) * 64];
+                f.b[y][s][0] = src[(y * 4 + s * 2) * 64 + lane];
+                f.b[y][s][1] = src[(y * 4 + s * 2 + 1) * 64 + lane];
             }
     };
     // workgroups walk the tile list with stride gridDim.x (the host launches about two workgroups per CU): the
@@ -362,12 +362,13 @@ __global__ __launch_bounds__(WAVES * 64) void bconvu_kernel(const IgemmParams p,
         for (int y = 0; y < NT; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][y][r] = 0.f;
+    if (tile == (int)blockIdx.x) {      // later tiles find their first taps in the ring already (look-ahead of the previous tile)
 #pragma unroll
-    for (int u = 0; u < U - 1; ++u) load_b(ring[u], u);
+        for (int u = 0; u < D; ++u) load_b(ring[u], u, cc_begin);
+    }
 
     const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = ow0 * p.sa_w + x.dw_min;
-    int seq0 = 0;
-    for (int cc = cc_begin; cc < cc_end; ++cc, seq0 += NTAPS) {
+    for (int cc = cc_begin; cc < cc_end; ++cc) {
         if (cc > cc_begin || !first) __syncthreads();
         first = false;
         bconv_stage_halo<NTHR>(p, x, halo, cc, n, ih0, iw0, tid);
@@ -382,7 +383,14 @@ __global__ __launch_bounds__(WAVES * 64) void bconvu_kernel(const IgemmParams p,
             }
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
-            load_b(ring[(t + U - 1) % U], seq0 + t + U - 1);
+            {   // look-ahead tap: same chunk, or the first taps of the next chunk (of the next tile after the last chunk)
+                const int tn = t + D;
+                const int ccn = cc + 1 < cc_end ? cc + 1 : cc_begin;
+                load_b(ring[tn % U], tn < NTAPS ? tn : tn - NTAPS, tn < NTAPS ? cc : ccn);
+            }
+            // keep the look-ahead load HERE: left alone, hipcc sinks it down to its first use four taps later and the
+            // ring degenerates into load-wait-multiply
+            __builtin_amdgcn_sched_barrier(0);
             const BSet& f = ring[t % U];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
