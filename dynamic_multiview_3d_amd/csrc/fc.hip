@@ -237,6 +237,20 @@ __global__ __launch_bounds__(256) void fc_stream_b3_kernel(const FcParams p) {
         store_a(rq[0], 0);
         __syncthreads();
         int buf = 0;
+        constexpr int NCH = 16;             // 4096-long reduction in 8 slices: straight-line code, exact s_waitcnt counts
+        if (c_end - c_begin == NCH) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                if (i + RING - 1 < NCH) {
+                    load_a(rq[(i + RING - 1) % RING], c_begin + i + RING - 1);
+                    load_b(bq[(i + RING - 1) % RING], c_begin + i + RING - 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the look-ahead loads at the top of the step
+                mma(bq[i % RING], i & 1);
+                if (i + 1 < NCH) store_a(rq[(i + 1) % RING], (i + 1) & 1);
+                __syncthreads();
+            }
+        } else
         for (int c = c_begin; c < c_end; c += RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u) {
