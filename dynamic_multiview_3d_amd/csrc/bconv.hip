@@ -473,23 +473,19 @@ __global__ __launch_bounds__(512) void bconvw_kernel(const IgemmParams p, const 
         struct BSet { uint4 b[2][2]; };
         BSet ring[U];
         uint4 a[MT][2][2];
-        const uint4* wf_lane = Wf + (int64_t)blockIdx.y * 256 + lane;
-        const int total_seq = chunks * NTAPS;
-        auto load_b = [&](BSet& f, int seq) {
-            seq = seq < total_seq ? seq : seq - total_seq;           // wraps into the next tile (same filters)
-            const int cc = seq / NTAPS;
-            const int t = seq - cc * NTAPS;
-            const uint4* src = wf_lane + ((int64_t)t * chunks + cc) * ntiles * 256;
+        const uint4* wf_base = Wf + (int64_t)blockIdx.y * 256;
+        const int64_t tap_stride = (int64_t)chunks * ntiles * 256, chunk_stride = (int64_t)ntiles * 256;
+        auto load_b = [&](BSet& f, int t, int cc) {
+            const uint4* src = wf_base + t * tap_stride + cc * chunk_stride;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { f.b[s][0] = src[(s * 2) * 64]; f.b[s][1] = src[(s * 2 + 1) * 64]; }
+            for (int s = 0; s < 2; ++s) { f.b[s][0] = src[(s * 2) * 64 + lane]; f.b[s][1] = src[(s * 2 + 1) * 64 + lane]; }
         };
 #pragma unroll
-        for (int u = 0; u < U - 1; ++u) load_b(ring[u], u);
+        for (int u = 0; u < U - 1; ++u) load_b(ring[u], u, 0);
         __syncthreads();                                             // end barrier of the prologue: halo of unit 0 is in buffer 0
         for (int u = 0; u < nunits; ++u) {
             const int cc = u % chunks;
             const unsigned char* halo = hbuf0 + (u & 1) * halo_bytes;
-            const int seq0 = cc * NTAPS;
             if (cc == 0) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
@@ -507,7 +503,12 @@ __global__ __launch_bounds__(512) void bconvw_kernel(const IgemmParams p, const 
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
                 if (t == TMID) __syncthreads();                      // mid barrier
-                load_b(ring[(t + U - 1) % U], seq0 + t + U - 1);
+                {   // look-ahead tap: this chunk, or the first taps of the next unit's chunk
+                    const int tn = t + U - 1;
+                    const int ccn = cc + 1 < chunks ? cc + 1 : 0;
+                    load_b(ring[tn % U], tn < NTAPS ? tn : tn - NTAPS, tn < NTAPS ? cc : ccn);
+                }
+                __builtin_amdgcn_sched_barrier(0);               // keep the look-ahead load here (hipcc sinks it to its first use)
                 const BSet& f = ring[t % U];
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
