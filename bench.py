@@ -73,7 +73,20 @@ def cpu_baseline(batch=8, steps=3):
     for _ in range(steps):
         omodels.step(builder, variables, adam, feeds)
     dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+    # threads actually used: the BLAS pool numpy multiplies on (im2col GEMMs dominate), bounded by this process's CPU set
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count()
+    cores = avail
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [i.get('num_threads', 0) for i in threadpool_info() if i.get('user_api') == 'blas']
+        if blas:
+            cores = min(avail, max(blas))
+    except Exception:
+        pass
+    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "numpy/BLAS oracle, AppearanceFlowModel fwd+bwd+Adam, %d timed steps at batch %d after 1 warm-up "
                       "(TensorFlow 1.3 reference cannot run offline)" % (steps, batch)}
 
@@ -149,6 +162,18 @@ def main():
                 adam_ms.append(g.adam_timing)
             g.adam_timing = None
 
+    def serial_step(adam_events):
+        """Kernel-table pass: the same launches on ONE stream (no side streams, Adam as a single launch behind the
+        reverse pass), so that every event-bracketed duration is the kernel's own and the shares add up to the step."""
+        g.run_forward()
+        lib.plan_run(g.plan_bwd, torch.cuda.current_stream(dev).cuda_stream)
+        if world > 1:
+            g.allreduce_grads()
+        adam_events[0].record()
+        g.apply_adam()
+        adam_events[1].record()
+        adam_ms.append([tuple(adam_events)])
+
     def adam_collect():
         """mean ms per step over the steps timed so far (call after a synchronize); clears the list"""
         tot = [sum(a.elapsed_time(b) for a, b in step) for step in adam_ms]
@@ -171,8 +196,10 @@ def main():
                 k['ms'] += ms / runs
 
     timing = not args.no_kernel_timing
-    # ---- warm-up (untimed).  With kernel timing on, every launch of the warm-up steps after the first is
-    # bracketed with HIP events: that gives the per-kernel table and names the dominant kernel.
+    # ---- warm-up (untimed).  With kernel timing on, the warm-up steps after the first run the same launches on one
+    # stream with every launch bracketed by HIP events: that gives the per-kernel table (own durations, shares that
+    # add up) and names the dominant kernel.  The timed region then runs the product's multi-stream train step with
+    # events on that kernel's launches only.
     table = collections.OrderedDict()
     dominant = None
     if args.warmup > 0:
@@ -184,7 +211,7 @@ def main():
             lib.plan_profile(plan, 1)
         wev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.warmup - 1)]
         for i in range(args.warmup - 1):
-            one_step(wev[i])
+            serial_step(wev[i])
         torch.cuda.synchronize()
         collect(table)
         table['adam'] = dict(launches=1, flops=0.0, bytes=28.0 * g.flat_size, ms=adam_collect())
@@ -270,7 +297,8 @@ def main():
             try:
                 ent = json.load(open(tfile)).get(dom_name)
                 if ent:      # HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), FETCH_SIZE x2-corrected
-                    roof["traffic"] = ent["hbm_bytes_per_launch"]
+                    # per launch as counted in `launches_per_step` above (the optimiser is one logical launch here, 4-5 slices in the product)
+                    roof["traffic"] = round(ent["hbm_bytes_per_launch"] * (ent.get("launches_per_step") or dom['launches']) / dom['launches'])
                     roof["algorithmic_bytes_per_launch"] = round(dom['bytes'] / dom['launches'])
             except Exception:
                 pass
@@ -280,7 +308,7 @@ def main():
         conv_fl = sum(k['flops'] for k in mfma.values())
         hbm = {n: k for n, k in table.items() if k['flops'] <= 0 and k['bytes'] > 0}
         hbm_ms = sum(k['ms'] for k in hbm.values())
-        out["stack"] = {"source": "HIP events around every launch during the warm-up steps",
+        out["stack"] = {"source": "HIP events around every launch during the warm-up steps, streams serialized (each duration is the kernel's own)",
                         "gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
                         "mfma_kernels_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                         "mfma_kernels_frac_of_f32_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

@@ -51,6 +51,9 @@ LABEL = {
 }
 
 
+COUNTS = {}
+
+
 def means(d, counter):
     f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
     acc = collections.OrderedDict()
@@ -60,6 +63,9 @@ def means(d, counter):
             continue
         k = k.replace('void mv3d::', '').split('(')[0]
         acc.setdefault(k, []).append(float(r['Counter_Value']))
+    steps = max(len(acc.get('mv3d::bconv_split_all_kernel', [])), 1)       # one filter conversion per step
+    for k, v in acc.items():
+        COUNTS[k] = len(v) / steps
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -71,6 +77,7 @@ for k in fetch:
     wb = int(write.get(k, 0.0) * 1024)
     out[LABEL.get(k, k)] = {
         'hbm_bytes_per_launch': fb + wb, 'fetch_bytes_x2_corrected': fb, 'write_bytes': wb, 'cxx_kernel': k,
+        'launches_per_step': round(COUNTS.get(k, 0), 2),
         'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB units, FETCH_SIZE doubled per '
                   "MI355X_MICROARCH.md HBM section; mean over the kernel's launches"}
 json.dump(out, sys.stdout, indent=1)
