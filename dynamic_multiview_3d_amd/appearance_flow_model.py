@@ -3,8 +3,9 @@
 Same constructor signature, method names (buildModel, build_loss, decodeAngle) and attributes
 (image0, image1, disp, flow_field, warp_pts, gen, loss, train_op, t_vars, saver); the TF session
 step becomes train_step()/forward() (model_base.py).  Inputs are fed (feed-style API of
-mv3d/nobg_nodm.py:146-150); the TFRecord reader is a later row of SURVEY 8f, so load_tfrec only
-selects whether `conf['data_dir']` is looked at (it is not, yet).
+mv3d/nobg_nodm.py:146-150): the reference wires its TFRecord queue into the graph when load_tfrec is set
+(appearance_flow_model.py:30-34); here the reader (read_tf_records.py, no TensorFlow) is a host-side feeder
+that the train driver connects to train_step(**batch), so load_tfrec has no effect on the graph itself.
 """
 from .tf_utils import *                     # noqa: F401,F403  (same star-import as the reference)
 from .model_base import ModelBase, AdamOptimizer

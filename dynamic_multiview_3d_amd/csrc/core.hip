@@ -205,6 +205,34 @@ int mv3d_plan_profile_reset(mv3d_plan* p) {
     return MV3D_OK;
 }
 
+// CRC-32C (Castagnoli), the checksum of the TFRecord framing (host only; slicing-by-8 tables built on first use).
+uint32_t mv3d_crc32c(const void* data, size_t n) {
+    static uint32_t T[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    uint32_t c = 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^
+            T[3][hi & 0xFF] ^ T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF];
+    return c ^ 0xFFFFFFFFu;
+}
+
 int mv3d_plan_op_info(const mv3d_plan* p, int i, const char** name, double* flops, double* bytes, double* total_ms, int* runs) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_op_info: bad index");
     const PlanOp& o = p->ops[i];

@@ -106,6 +106,7 @@ def main(argv=None):
     ap.add_argument('--device', default='0', help='GPU index (the reference sets CUDA_VISIBLE_DEVICES)')
     ap.add_argument('--pretrained', default=None, help='path to model file from which to resume training')
     ap.add_argument('--num_iterations', type=int, default=None, help='override conf["num_iterations"]')
+    ap.add_argument('--synthetic', action='store_true', help='ignore conf["data_dir"] and train on synthetic batches')
     FLAGS = ap.parse_args(argv)
 
     conf = load_conf(FLAGS.hyper)
@@ -124,8 +125,19 @@ def main(argv=None):
     if world > 1:
         model.enable_data_parallel(world)
     saver = model.saver
-    train_data = SyntheticData(model, seed=rank)
-    val_data = SyntheticData(model, seed=10_000 + rank, pool=1)
+    data_dir = conf.get('data_dir')
+    if not FLAGS.synthetic and data_dir and os.path.isdir(data_dir) and os.listdir(data_dir):
+        # the reference's shards (multi_view_model/utils/read_tf_records.py:15-85), read without TensorFlow
+        from .read_tf_records import build_tfrecord_input
+        train_data = build_tfrecord_input(conf, model, training=True, seed=rank, rank=rank, world=world)
+        val_data = build_tfrecord_input(conf, model, training=False, seed=10_000 + rank)
+        if rank == 0:
+            print('reading TFRecord shards from', data_dir)
+    else:
+        if rank == 0:
+            print('no TFRecord shards at conf["data_dir"] = %r: training on synthetic batches' % (data_dir,))
+        train_data = SyntheticData(model, seed=rank)
+        val_data = SyntheticData(model, seed=10_000 + rank, pool=1)
 
     itr_0 = 0
     if FLAGS.pretrained is not None:

@@ -65,6 +65,9 @@ typedef struct mv3d_epilogue {
 
 const char* mv3d_version(void);
 const char* mv3d_last_error(void);
+/* CRC-32C of a host buffer: the record checksum of the reference's TFRecord shards (multi_view_model/utils/read_tf_records.py:46-48
+ * reads them through tf.TFRecordReader); used by dynamic_multiview_3d_amd/read_tf_records.py */
+uint32_t mv3d_crc32c(const void* data, size_t n);
 
 /* ---- conv2d: tf.nn.conv2d(x, w, [1,sh,sw,1], 'SAME') + b  (tf_utils.py:81-82) ------------- */
 /* y[N,Ho,Wo,K] = epi( x[N,H,W,C] (*) w[kh,kw,C,K] ) */
