@@ -295,7 +295,10 @@ class TFRecordInput:
             raise RuntimeError("TFRecord input thread failed: %r" % (self._err,))
         if ev is not None:
             import torch
-            torch.cuda.current_stream(self.device).wait_event(ev)       # the upload ran on the reader's stream
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)                                           # the upload ran on the reader's stream
+            for t in out.values():
+                t.record_stream(cur)     # allocated on the reader's stream, consumed on this one: keep the block until then
         return out
 
     def close(self):

@@ -227,3 +227,35 @@ def test_train_driver_runs_saves_and_resumes(tmp_path):
     model2 = train.main(['--hyper', str(conf_py), '--pretrained', str(out / 'model30'), '--num_iterations', '33'])
     rows = [json.loads(l) for l in open(out / 'train_log.jsonl')]
     assert [r['itr'] for r in rows if 'training_loss' in r][-1] == 30              # resumed at 30: logs itr 30 again
+
+
+def test_train_driver_reads_tfrecord_shards(tmp_path):
+    """conf['data_dir'] with TFRecord shards in the reference's format feeds the train loop
+    (background reader thread, pinned upload on its own stream); the first batch the model sees is the first two
+    records of the only training file."""
+    from dynamic_multiview_3d_amd import train, read_tf_records as R
+    data = tmp_path / 'data'
+    data.mkdir()
+    rng = np.random.default_rng(0)
+    first = []
+    for f in range(2):
+        with R.TFRecordWriter(str(data / ('%d.tfrecords' % f))) as w:
+            for i in range(6):
+                img0 = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)
+                if f == 0 and i < 2:
+                    first.append(img0)
+                w.write(R.serialize_example({'image0': img0.tobytes(), 'image1': rng.integers(0, 256, (128, 128, 3), dtype=np.uint8).tobytes(),
+                                             'depth0': bytes(128 * 128), 'depth1': bytes(128 * 128),
+                                             'displacement': rng.uniform(-1, 1, 2).astype(np.float32)}))
+    conf_py = tmp_path / 'conf.py'
+    conf_py.write_text(
+        "import os\nfrom appearance_flow_model import AppearanceFlowModel\n"
+        "configuration = {'experiment_name': 't', 'data_dir': %r, 'output_dir': os.path.dirname(os.path.realpath(__file__)) + '/modeldata',\n"
+        "  'num_iterations': 12, 'batch_size': 2, 'learning_rate': 1e-4, 'train_val_split': 0.5, 'model': AppearanceFlowModel}\n" % str(data))
+    model = train.main(['--hyper', str(conf_py)])
+    import json
+    rows = [json.loads(l) for l in open(tmp_path / 'modeldata' / 'train_log.jsonl')]
+    losses = [r['training_loss'] for r in rows if 'training_loss' in r]
+    assert len(losses) == 2 and all(np.isfinite(losses))
+    # 13 steps x 2 records over a 6-record training file: the 13th batch wraps to records 0, 1 of file 0 again
+    np.testing.assert_array_equal(model.image0.numpy(), np.stack(first).astype(np.float32) / np.float32(255))
