@@ -691,6 +691,11 @@ static bool thin_filtgrad_plan(const mv3d_conv_geom* g, ThinFgParams& p, int* ns
         lds = (size_t)(((p.IR * p.IW * p.C + 3) & ~3) + p.TR * g->Wo * 32) * sizeof(float);
         if (lds <= 52 * 1024) break;
     }
+    {   // the end-of-kernel exchange of the four waves' partials reuses the staging area: [3][NJ*8 + 8][64] floats
+        const int nj = cdiv(p.nrows, 16);
+        const int NJ = nj <= 2 ? 2 : (nj <= 4 ? 4 : (nj <= 5 ? 5 : 7));
+        lds = std::max(lds, (size_t)3 * (NJ * 8 + 8) * 64 * sizeof(float));
+    }
     if (lds > 64 * 1024) return false;
     p.blocks_per_img = cdiv(g->Ho, p.TR);
     p.blocks_total = g->N * p.blocks_per_img;

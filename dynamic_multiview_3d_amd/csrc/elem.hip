@@ -65,25 +65,37 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleParams p) {
 }
 
 // ---------------------------------------------------------------- pixel losses (tf_utils.py:18-23)
-__global__ __launch_bounds__(256) void pixel_loss_kernel(int64_t pixels, int ch, const float* __restrict__ a,
-                                                        const float* __restrict__ b, const float* __restrict__ mask,
-                                                        int kind, float weight, float* loss, float* __restrict__ grad) {
-    const int64_t total = pixels * ch;
-    const float gscale = (kind == 2 ? 2.0f : 1.0f) * weight / (float)pixels;
+struct PixelLossParams {
+    int64_t pixels; int ch;
+    const float* a; int a_ld;
+    const float* b; int b_ld; float b_scale;
+    const float* mask; int mask_ld;
+    int kind; float weight;
+    float* loss; float* grad; int grad_ld;
+};
+
+// a, b, grad: [pixels][ch] views with pixel strides *_ld (channel slices of wider tensors, mv3d/nobg_dm.py:85-92);
+// b is read as b * b_scale (mv3d/bg_nodm.py:88: gt_sm * 0.75); mask: one value per pixel (stride mask_ld)
+__global__ __launch_bounds__(256) void pixel_loss_kernel(const PixelLossParams p) {
+    const int64_t total = p.pixels * p.ch;
+    const float gscale = (p.kind == 2 ? 2.0f : 1.0f) * p.weight / (float)p.pixels;
     float sum = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const float m = mask ? mask[i / ch] : 1.0f;
-        const float d = (a[i] - b[i]) * m;
+        const int64_t pix = i / p.ch;
+        const int c = (int)(i - pix * p.ch);
+        const float m = p.mask ? p.mask[pix * p.mask_ld] : 1.0f;
+        const float bv = p.b_scale == 1.0f ? p.b[pix * p.b_ld + c] : p.b[pix * p.b_ld + c] * p.b_scale;
+        const float d = (p.a[pix * p.a_ld + c] - bv) * m;
         float g;
-        if (kind == 2) { sum += d * d; g = d * m * gscale; }
+        if (p.kind == 2) { sum += d * d; g = d * m * gscale; }
         else { sum += fabsf(d); g = ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) * m * gscale; }
-        if (grad) grad[i] = g;
+        if (p.grad) p.grad[pix * p.grad_ld + c] = g;
     }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
     __shared__ float s_part[4];
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (weight / (float)pixels));
+    if (threadIdx.x == 0) atomicAdd(p.loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (p.weight / (float)p.pixels));
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t count, float v) {
@@ -192,16 +204,24 @@ int mv3d_warp_resample_bwd(int N, int H, int W, int Hs, int Ws, int C, const voi
     });
 }
 
-int mv3d_pixel_loss(int64_t pixels, int ch, const void* a, const void* b, const void* mask, int kind, float weight,
-                    void* loss_accum, void* grad, void* stream) {
+int mv3d_pixel_loss_strided(int64_t pixels, int ch, const void* a, int a_ld, const void* b, int b_ld, float b_scale,
+                            const void* mask, int mask_ld, int kind, float weight, void* loss_accum, void* grad, int grad_ld,
+                            void* stream) {
     if (pixels <= 0 || ch <= 0 || (kind != 1 && kind != 2)) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: bad arguments");
     if (!a || !b || !loss_accum) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: null pointer");
+    if (a_ld < ch || b_ld < ch || (grad && grad_ld < ch) || (mask && mask_ld < 1)) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: pixel stride smaller than the channel count");
+    PixelLossParams p = {pixels, ch, (const float*)a, a_ld, (const float*)b, b_ld, b_scale, (const float*)mask, mask_ld, kind, weight,
+                         (float*)loss_accum, (float*)grad, grad_ld};
     const int blocks = (int)std::min<int64_t>(cdiv64(pixels * ch, 256 * 8), 1024);
     return dispatch(stream, OpInfo{"pixel_loss", 0.0, (double)pixels * ch * (grad ? 12.0 : 8.0)}, [=](hipStream_t s) {
-        pixel_loss_kernel<<<blocks, 256, 0, s>>>(pixels, ch, (const float*)a, (const float*)b, (const float*)mask, kind, weight,
-                                                (float*)loss_accum, (float*)grad);
+        pixel_loss_kernel<<<blocks, 256, 0, s>>>(p);
         return launched("pixel_loss_kernel");
     });
+}
+
+int mv3d_pixel_loss(int64_t pixels, int ch, const void* a, const void* b, const void* mask, int kind, float weight,
+                    void* loss_accum, void* grad, void* stream) {
+    return mv3d_pixel_loss_strided(pixels, ch, a, ch, b, ch, 1.0f, mask, 1, kind, weight, loss_accum, grad, ch, stream);
 }
 
 int mv3d_fill(void* dst, int64_t count, float value, void* stream) {

@@ -182,8 +182,8 @@ class ScalarExpr:
 
 
 class LossTerm:
-    def __init__(self, a, b, kind, mask=None):
-        self.a, self.b, self.kind, self.mask = a, b, kind, mask
+    def __init__(self, a, b, kind, mask=None, b_scale=1.0):
+        self.a, self.b, self.kind, self.mask, self.b_scale = a, b, kind, mask, float(b_scale)
 
 
 # =============================================================================================== nodes
@@ -543,12 +543,13 @@ class Graph:
         if self.loss_expr is None:
             return
         for w, term in self.loss_expr.terms:
-            a = term.a
-            if a.ld != a.C or term.b.ld != term.b.C:
-                raise NotImplementedError("loss on a channel-sliced tensor")
+            a, b, m = term.a, term.b, term.mask
+            if a.C != b.C or a.rows != b.rows:
+                raise ValueError("loss operands of different shapes")
             grad = a.grad_ptr if (with_grad and a.requires_grad) else None
-            self.lib.pixel_loss(a.rows, a.C, a.ptr, term.b.ptr, term.mask.ptr if term.mask is not None else None,
-                                term.kind, float(w), self.loss_buf.data_ptr(), grad, self.stream)
+            self.lib.pixel_loss_strided(a.rows, a.C, a.ptr, a.ld, b.ptr, b.ld, term.b_scale,
+                                        m.ptr if m is not None else None, m.ld if m is not None else 1,
+                                        term.kind, float(w), self.loss_buf.data_ptr(), grad, a.ld, self.stream)
             if grad is not None:
                 _note_grad_written(a, False)
 

@@ -36,20 +36,67 @@ def _same_out(size, s):
 
 
 # ------------------------------------------------------------------------------------------------ losses
+class _Scaled:
+    """x * c for a constant c: a loss target only (mv3d/bg_nodm.py:88 `gt_sm = gt_sm * 0.75`); folded into the loss kernel."""
+
+    def __init__(self, x, c):
+        self.x, self.c = x, float(c)
+
+
+class _Masked:
+    """tf.multiply(x, mask) with a one-channel mask: a loss operand only (mv3d/bg_nodm.py:91); (a*m - b*m) is evaluated
+    as (a - b)*m inside the loss kernel."""
+
+    def __init__(self, x, mask):
+        self.x, self.mask = x, mask
+
+
+def scale(x, c):
+    return _Scaled(x, c)
+
+
+def multiply(x, mask):
+    if mask.C != 1:
+        raise NotImplementedError("multiply: only a one-channel mask is supported")
+    return _Masked(x, mask)
+
+
+def _loss_term(input1, input2, kind, mask=None):
+    for v in (input1, input2):
+        if isinstance(v, _Masked):
+            if mask is not None and mask is not v.mask:
+                raise NotImplementedError("loss operands multiplied by different masks")
+            mask = v.mask
+    a, b = (v.x if isinstance(v, _Masked) else v for v in (input1, input2))
+    # the differentiated operand goes first; both reference losses are symmetric in their arguments
+    a_grad = (a.x if isinstance(a, _Scaled) else a).requires_grad
+    b_grad = (b.x if isinstance(b, _Scaled) else b).requires_grad
+    if b_grad and not a_grad:
+        a, b = b, a
+    elif a_grad and b_grad:
+        raise NotImplementedError("loss between two differentiated tensors")
+    if isinstance(a, _Scaled):
+        raise NotImplementedError("scaling the differentiated operand of a loss")
+    b_scale = 1.0
+    if isinstance(b, _Scaled):
+        b, b_scale = b.x, b.c
+    return ScalarExpr([(1.0, LossTerm(a, b, kind, mask, b_scale))])
+
+
 def euclidean_loss(input1, input2):
     """tf_utils.py:18-19: reduce_mean(reduce_sum(pow(a-b, 2), 3))."""
-    return ScalarExpr([(1.0, LossTerm(input1, input2, 2))])
+    return _loss_term(input1, input2, 2)
 
 
 def l1_loss(input1, input2):
     """tf_utils.py:22-23: reduce_mean(reduce_sum(abs(a-b), 3))."""
-    return ScalarExpr([(1.0, LossTerm(input1, input2, 1))])
+    return _loss_term(input1, input2, 1)
 
 
 def masked_euclidean_loss(input1, input2, mask):
     """reduce_mean(reduce_sum(pow((a-b)*mask, 2), 3)) -- the inline expression of
     multi_view_model/multiobject_appflow.py:239-242 (mask is [B,H,W,1])."""
-    return ScalarExpr([(1.0, LossTerm(input1, input2, 2, mask))])
+    return _loss_term(input1, input2, 2, mask)
 
 
 # ------------------------------------------------------------------------------------------------ activations
@@ -214,17 +261,24 @@ def concat(values=None, axis=None):
 
 
 def split(value, num_or_size_splits, axis):
-    """tf.split into equal channel slices (views)."""
+    """tf.split into channel slices (views): a count (equal slices) or a list of sizes -- the latter also stands in for
+    the tf.slice pairs of mv3d/nobg_dm.py:85-89 (colour = channels 0..2, depth / mask = channel 3)."""
     g = current_graph()
     _check_usable(value)
     if axis not in (len(value.shape) - 1, -1):
         raise NotImplementedError("split on a non-channel axis")
-    num = int(num_or_size_splits)
-    if value.C % num:
-        raise ValueError("channels not divisible")
-    c = value.C // num
-    outs = [g.new_tensor(value.shape[:-1] + (c,), storage=value.storage, ch_off=value.ch_off + i * c, act=value.act,
-                         leak=value.leak, requires_grad=value.requires_grad) for i in range(num)]
+    if isinstance(num_or_size_splits, (list, tuple)):
+        sizes = [int(c) for c in num_or_size_splits]
+        if sum(sizes) != value.C or min(sizes) < 1:
+            raise ValueError("split sizes %s do not add up to %d channels" % (sizes, value.C))
+    else:
+        num = int(num_or_size_splits)
+        if num < 1 or value.C % num:
+            raise ValueError("channels not divisible")
+        sizes = [value.C // num] * num
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    outs = [g.new_tensor(value.shape[:-1] + (c,), storage=value.storage, ch_off=value.ch_off + o, act=value.act,
+                         leak=value.leak, requires_grad=value.requires_grad) for c, o in zip(sizes, offs)]
     node = g.add(ViewNode([value], list(outs)))
     for o in outs:
         o.producer = node

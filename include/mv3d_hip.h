@@ -154,6 +154,12 @@ int mv3d_warp_resample_bwd(int N, int H, int W, int Hs, int Ws, int C, const voi
  * loss_accum must be zeroed by the caller before the first term (mv3d_fill). */
 int mv3d_pixel_loss(int64_t pixels, int ch, const void* a, const void* b, const void* mask, int kind, float weight,
                     void* loss_accum, void* grad, void* stream);
+/* same on channel-slice views (pixel strides *_ld), with the target read as b * b_scale and a per-pixel mask of stride
+ * mask_ld: the mv3d losses slice a 4-channel prediction / target into colour and depth or mask parts
+ * (mv3d/nobg_dm.py:85-92, mv3d/bg_nodm.py:85-93: gt_sm * 0.75, tf.multiply(.., sm)) */
+int mv3d_pixel_loss_strided(int64_t pixels, int ch, const void* a, int a_ld, const void* b, int b_ld, float b_scale,
+                            const void* mask, int mask_ld, int kind, float weight, void* loss_accum, void* grad, int grad_ld,
+                            void* stream);
 int mv3d_fill(void* dst, int64_t count, float value, void* stream);
 
 /* ---- Adam: tf.train.AdamOptimizer ApplyAdam (appearance_flow_model.py:77) -------

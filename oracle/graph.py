@@ -223,7 +223,9 @@ class Tape:
         return y
 
     def split(self, x, num, axis):
-        outs = [Node(p.copy()) for p in np.split(x.v, num, axis=axis)]
+        """tf.split: `num` equal parts, or a list of sizes (stands in for the tf.slice pairs of mv3d/nobg_dm.py:85-89)."""
+        sections = num if not isinstance(num, (list, tuple)) else list(np.cumsum(num)[:-1])
+        outs = [Node(p.copy(), needs_grad=x.needs_grad) for p in np.split(x.v, sections, axis=axis)]
         keep = list(outs)          # callers pop() from the returned list (main_model.py:131-137)
 
         def back():
@@ -252,6 +254,12 @@ class Tape:
     def scale(self, x, c):
         y = Node(x.v * self.dtype(c))
         self._rec([y], lambda: x.acc(y.g * self.dtype(c)))
+        return y
+
+    def multiply(self, x, m):
+        """tf.multiply(x, mask) with a broadcast one-channel constant mask (mv3d/bg_nodm.py:91)."""
+        y = Node(x.v * m.v, needs_grad=x.needs_grad)
+        self._rec([y], lambda: x.acc(y.g * m.v) if x.needs_grad else None)
         return y
 
     def add(self, a, b):

@@ -180,6 +180,65 @@ def base_prediction(t, conf, image0, image1, dimage0, dimage1, disp, build_loss=
     return out
 
 
+# --------------------------------------------------------------------------- mv3d (direct prediction, the original models)
+def mv3d(t, variant, images1, images2, labels, build_loss=True):
+    """mv3d.buildModel of dyn_mult_view/mv3d/nobg_nodm.py:31-95, nobg_dm.py:30-96, bg_nodm.py:30-98: encoder ->
+    fc bottleneck joined with the 5-d view label -> decoder -> tanh image (+ depth map / + silhouette mask)."""
+    B = labels.v.shape[0]
+    bg = variant == 'bg_nodm'
+    k5 = (3, 3) if bg else (5, 5)            # bg_nodm swaps the 5x5 stride-1 convs for 3x3 ones and renames them *_1
+    sfx = '_1' if bg else '_0'
+    e0 = t.lrelu(t.conv2d_msra(images1, 16 if bg else 32, 5, 5, 2, 2, "e0"))
+    e0_0 = t.lrelu(t.conv2d_msra(e0, 32, k5[0], k5[1], 1, 1, "e0" + sfx))
+    e1 = t.lrelu(t.conv2d_msra(e0_0, 32, 5, 5, 2, 2, "e1"))
+    e1_0 = t.lrelu(t.conv2d_msra(e1, 32, k5[0], k5[1], 1, 1, "e1" + sfx))
+    e2 = t.lrelu(t.conv2d_msra(e1_0, 64, k5[0], k5[1], 2, 2, "e2"))
+    e2_0 = t.lrelu(t.conv2d_msra(e2, 64, k5[0], k5[1], 1, 1, "e2" + sfx))
+    e3 = t.lrelu(t.conv2d_msra(e2_0, 128, 3, 3, 2, 2, "e3"))
+    e3_0 = t.lrelu(t.conv2d_msra(e3, 128, 3, 3, 1, 1, "e3" + sfx))
+    e4 = t.lrelu(t.conv2d_msra(e3_0, 256, 3, 3, 2, 2, "e4"))
+    e4_0 = t.lrelu(t.conv2d_msra(e4, 256, 3, 3, 1, 1, "e4" + sfx))
+    e5 = t.lrelu(t.linear_msra(t.reshape(e4_0, [B, 4096]), 4096, "fc1"))
+    a0 = t.lrelu(t.linear_msra(labels, 64, "a0"))
+    a1 = t.lrelu(t.linear_msra(a0, 64, "a1"))
+    a2 = t.lrelu(t.linear_msra(a1, 64, "a2"))
+    a3 = t.lrelu(t.linear_msra(t.concat(1, [e5, a2]), 4096, "a3"))
+    a4 = t.lrelu(t.linear_msra(a3, 4096, "a4"))
+    a5 = t.lrelu(t.linear_msra(a4, 4096, "a5"))
+    d4 = t.lrelu(t.deconv2d_msra(t.reshape(a5, [B, 4, 4, 256]), [B, 8, 8, 128], 3, 3, 2, 2, "d4"))
+    d4_0 = t.lrelu(t.conv2d_msra(d4, 128, 3, 3, 1, 1, "d4" + sfx))
+    d3 = t.lrelu(t.deconv2d_msra(d4_0, [B, 16, 16, 64], 3, 3, 2, 2, "d3"))
+    d3_0 = t.lrelu(t.conv2d_msra(d3, 64, k5[0], k5[1], 1, 1, "d3" + sfx))
+    d2 = t.lrelu(t.deconv2d_msra(d3_0, [B, 32, 32, 32], 5, 5, 2, 2, "d2"))
+    d2_0 = t.lrelu(t.conv2d_msra(d2, 32 if bg else 64, k5[0], k5[1], 1, 1, "d2" + sfx))
+    d1 = t.lrelu(t.deconv2d_msra(d2_0, [B, 64, 64, 32], 5, 5, 2, 2, "d1"))
+    d1_0 = t.lrelu(t.conv2d_msra(d1, 32, k5[0], k5[1], 1, 1, "d1" + sfx))
+    nout = 3 if variant == 'nobg_nodm' else 4
+    if bg:
+        d0 = t.lrelu(t.deconv2d_msra(d1_0, [B, 128, 128, 16], 5, 5, 2, 2, "d0"))
+        gen = t.tanh(t.conv2d_msra(d0, 4, 3, 3, 1, 1, "d0_1"))
+    else:
+        gen = t.tanh(t.deconv2d_msra(d1_0, [B, 128, 128, nout], 5, 5, 2, 2, "d0"))
+    out = OrderedDict(gen=gen)
+    if build_loss:
+        if variant == 'nobg_nodm':
+            out['loss'] = t.euclidean_loss(gen, images2)
+        else:
+            gt_cm, gt_x = t.split(images2, [3, 1], 3)
+            pr_cm, pr_x = t.split(gen, [3, 1], 3)
+            if variant == 'nobg_dm':
+                out['loss'] = t.add(t.euclidean_loss(gt_cm, pr_cm), t.scale(t.l1_loss(gt_x, pr_x), 0.1))
+            else:
+                sm = gt_x
+                out['loss'] = t.add(t.euclidean_loss(t.multiply(gt_cm, sm), t.multiply(pr_cm, sm)),
+                                    t.scale(t.euclidean_loss(t.scale(gt_x, 0.75), pr_x), 0.1))
+    return out
+
+
+def mv3d_builder(variant, build_loss=True):
+    return lambda t, n: mv3d(t, variant, n['images1'], n['images2'], n['labels'], build_loss)
+
+
 # --------------------------------------------------------------------------- MultiObjectAppFlow
 def multiobject_appflow(t, conf, inp, build_loss=True):
     """MultiObjectAppFlow.buildModel/build_loss (multiobject_appflow.py:123-286).

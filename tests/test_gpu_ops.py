@@ -32,6 +32,8 @@ CONV_CASES = [  # n, h, w, c, k, ksz, s
     (8, 4, 4, 256, 256, 3, 1),       # e4_0
     (1, 7, 9, 5, 20, 3, 2),          # ragged: odd sizes, channels not multiples of 4
     (2, 128, 128, 1, 32, 5, 2),      # depth / mask tower e0
+    (2, 128, 128, 4, 32, 5, 2),      # 4 input channels (rgb + depth)
+    (2, 128, 128, 16, 4, 3, 1),      # mv3d bg_nodm d0_1: 16 -> 4 channels, 3x3
     (2, 128, 128, 3, 16, 3, 2),      # tinghui e0
     (1, 16, 16, 128, 64, 5, 1),      # d3_0 with 2 decoders (Cout 128 -> here reversed sizes)
     (2, 4, 4, 320, 256, 3, 1),       # fully_conv e4_1 (256+64 in)
@@ -80,6 +82,7 @@ DECONV_CASES = [  # n, hi, wi, cin(feature side K), cout(image side C), ksz, s
     (2, 64, 64, 32, 2, 5, 2),        # flow_field (thin VALU path)
     (2, 64, 64, 32, 3, 5, 2),        # rgb head
     (2, 64, 64, 32, 1, 5, 2),        # depth / mask head
+    (2, 64, 64, 32, 4, 5, 2),        # mv3d rgb + depth / silhouette head (4 channels)
     (2, 32, 32, 16, 2, 3, 1),        # tinghui flow head (stride 1)
     (1, 3, 5, 8, 6, 5, 2),           # ragged
     (2, 8, 8, 32, 128, 3, 2),        # tinghui d3

@@ -64,6 +64,26 @@ def test_base_prediction_graph():
     assert variables['dec_image1/d0/w'].shape == (5, 5, 3, 32)
 
 
+def mv3d_feeds(rng, b, variant):
+    f = appflow_feeds(rng, b)
+    images2 = f['image1'] * 2.0 - 1.0                       # tanh range
+    if variant != 'nobg_nodm':
+        extra = (f['image0'][..., :1] > 0.5).astype(np.float32) if variant == 'bg_nodm' else f['image0'][..., :1] * 2.0 - 1.0
+        images2 = np.concatenate([images2, extra], axis=3)
+    labels = rng.uniform(-1, 1, (b, 5)).astype(np.float32)
+    return {'images1': f['image0'], 'images2': images2.astype(np.float32), 'labels': labels}
+
+
+@pytest.mark.parametrize("variant,nvars,nparams", [('nobg_nodm', 47, 69536224), ('nobg_dm', 47, 69537024), ('bg_nodm', 49, 69260772)])
+def test_mv3d_graphs(variant, nvars, nparams):
+    """the direct-prediction mv3d networks (mv3d/nobg_nodm.py, nobg_dm.py, bg_nodm.py)."""
+    feeds = mv3d_feeds(np.random.default_rng(6), 2, variant)
+    variables, used = _compare(models.mv3d_builder(variant), feeds)
+    assert len(used) == nvars and sum(v.size for v in variables.values()) == nparams
+    assert used[-1] == ('d0_1/b' if variant == 'bg_nodm' else 'd0/w')
+    assert variables['d0/w'].shape == ((5, 5, 16, 32) if variant == 'bg_nodm' else (5, 5, 3 if variant == 'nobg_nodm' else 4, 32))
+
+
 @pytest.mark.parametrize("conf", [
     {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'gen_sep_images': '', 'fully_conv': ''},
     {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'predict_target_masks': 0.5},

@@ -103,7 +103,12 @@ class TorchTape:
         return TNode(torch.cat([v.t for v in values], dim=axis))
 
     def split(self, x, num, axis):
+        if isinstance(num, (list, tuple)):
+            return [TNode(p) for p in torch.split(x.t, list(num), dim=axis)]
         return [TNode(p) for p in torch.chunk(x.t, num, dim=axis)]
+
+    def multiply(self, x, m):
+        return TNode(x.t * m.t)
 
     def reshape(self, x, shape):
         return TNode(x.t.reshape(shape))
