@@ -28,7 +28,7 @@ VAL_INTERVAL = 500          # train.py:27
 SAVE_INTERVAL = 10000       # train.py:30
 
 _ALIASES = ('appearance_flow_model', 'highdim_angle', 'lowdim_angle', 'appearance_flow_tinghui', 'main_model',
-            'multiobject_appflow')
+            'multiobject_appflow', 'multiobject_main_model')
 
 
 def load_conf(conf_file):

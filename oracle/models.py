@@ -240,8 +240,10 @@ def mv3d_builder(variant, build_loss=True):
 
 
 # --------------------------------------------------------------------------- MultiObjectAppFlow
-def multiobject_appflow(t, conf, inp, build_loss=True):
-    """MultiObjectAppFlow.buildModel/build_loss (multiobject_appflow.py:123-286).
+def multiobject_appflow(t, conf, inp, build_loss=True, direct_color=False):
+    """MultiObjectAppFlow.buildModel/build_loss (multiobject_appflow.py:123-286); direct_color=True: the sibling
+    multiobject_main_model.Base_Prediction_Model (multiobject_main_model.py:106-270), whose colour outputs come from
+    3-channel tanh decoders instead of appearance-flow decoders -- everything else is shared.
     `inp` maps the 13 reader attribute names (multiobject_appflow.py:31-43) to Nodes."""
     B = inp['displacement'].v.shape[0]
     H = inp['image0'].v.shape[1]
@@ -285,10 +287,10 @@ def multiobject_appflow(t, conf, inp, build_loss=True):
     split_list = t.split(d3_0, num_decode, 3)
     if 'use_color' in conf:
         if 'combination_image' in conf:
-            out['gen_image1'] = _decode_flow(t, inp['image0'], split_list.pop(), 'dec_image1', B, H)
+            out['gen_image1'] = (_decode_direct(t, split_list.pop(), 'dec_image1', 3, B, H) if direct_color else _decode_flow(t, inp['image0'], split_list.pop(), 'dec_image1', B, H))
         if 'gen_sep_images' in conf:
-            out['gen_image1_only0'] = _decode_flow(t, inp['image0'], split_list.pop(), 'dec_image1_only0', B, H)
-            out['gen_image1_only1'] = _decode_flow(t, inp['image0'], split_list.pop(), 'dec_image1_only1', B, H)
+            out['gen_image1_only0'] = (_decode_direct(t, split_list.pop(), 'dec_image1_only0', 3, B, H) if direct_color else _decode_flow(t, inp['image0'], split_list.pop(), 'dec_image1_only0', B, H))
+            out['gen_image1_only1'] = (_decode_direct(t, split_list.pop(), 'dec_image1_only1', 3, B, H) if direct_color else _decode_flow(t, inp['image0'], split_list.pop(), 'dec_image1_only1', B, H))
     if 'use_depth' in conf:
         if 'combination_image' in conf:
             out['gen_depth1'] = _decode_direct(t, split_list.pop(), 'dec_dimage1_f', 1, B, H)
@@ -379,8 +381,8 @@ def base_prediction_builder(conf, build_loss=True):
                                         n.get('dimage1'), n['disp'], build_loss)
 
 
-def multiobject_builder(conf, build_loss=True):
-    return lambda t, n: multiobject_appflow(t, conf, n, build_loss)
+def multiobject_builder(conf, build_loss=True, direct_color=False):
+    return lambda t, n: multiobject_appflow(t, conf, n, build_loss, direct_color)
 
 
 def step(builder, variables, adam, feeds):

@@ -203,6 +203,23 @@ def test_multiobject_appflow(extra):
     _check_generic(model, omodels.multiobject_builder(conf), f, names)
 
 
+@pytest.mark.parametrize("extra", [
+    {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'gen_sep_images': '', 'masked_image_loss': '', 'fully_conv': ''},
+    {'use_color': '', 'combination_image': '', 'predict_target_masks': 0.5},
+])
+def test_multiobject_main_model(extra):
+    """multiobject_main_model.Base_Prediction_Model -- every output from a direct tanh decoder."""
+    from dynamic_multiview_3d_amd.multiobject_main_model import Base_Prediction_Model
+    from tests.synth import multiobj_feeds
+    conf = dict(extra, batch_size=2, learning_rate=1e-4)
+    model = Base_Prediction_Model(conf, load_tfrec=False, device='cuda')
+    assert model.graph.variables['dec_image1/d0/w'].shape == (5, 5, 3, 32)
+    f = multiobj_feeds(np.random.default_rng(5), 2)
+    names = {a: a for a in ('gen_image1', 'gen_image1_only0', 'gen_image1_only1', 'gen_depth1', 'gen_depth1_only0',
+                            'gen_depth1_only1', 'gen_image1_mask0', 'gen_image1_mask1') if getattr(model, a) is not None}
+    _check_generic(model, omodels.multiobject_builder(conf, direct_color=True), f, names)
+
+
 def test_train_driver_runs_saves_and_resumes(tmp_path):
     """the train.py loop (inclusive iteration range, final checkpoint, resume
     iteration parsed from the file name) on a tiny batch."""

@@ -94,6 +94,13 @@ def test_multiobject_graph(conf):
     _compare(models.multiobject_builder(conf), f)
 
 
+def test_multiobject_main_model_graph():
+    """multiobject_main_model.Base_Prediction_Model: colour outputs from direct 3-channel tanh decoders."""
+    conf = {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'gen_sep_images': '', 'masked_image_loss': '', 'fully_conv': ''}
+    variables, used = _compare(models.multiobject_builder(conf, direct_color=True), multiobj_feeds(np.random.default_rng(7), 2))
+    assert variables['dec_image1/d0/w'].shape == (5, 5, 3, 32) and variables['dec_depth1_only1/d0/w'].shape == (5, 5, 1, 32)
+
+
 def test_three_adam_steps_reduce_loss_and_are_deterministic():
     feeds = appflow_feeds(np.random.default_rng(6), 2)
     builder = models.appearance_flow_builder('base')
