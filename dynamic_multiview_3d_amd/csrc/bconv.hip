@@ -216,10 +216,18 @@ __global__ __launch_bounds__(WAVES * 64) void bconv_kernel(const IgemmParams p, 
                 f.b[y][s][1] = src[(y * 4 + s * 2 + 1) * 64];
             }
     };
-    auto load_a = [&](BFrags<MT, NT>& f, int t) {
+    // LDS byte offset of a tap, fetched one tap early
+    // (lane t of every wave keeps tap t's offset; v_readlane with the wave-uniform tap index costs no memory access)
+    int lane_off;
+    {
+        const IgemmTap tap = p.taps[lane < x.ntaps_total ? lane : 0];
+        lane_off = (tap.dh - x.dh_min) * x.row_bytes + (tap.dw - x.dw_min) * BC_PIXB;
+    }
+    auto tap_off = [&](int t) {
         t = t < tap_hi ? t : tap_hi - 1;
-        const IgemmTap tap = p.taps[t];
-        const int off = (tap.dh - x.dh_min) * x.row_bytes + (tap.dw - x.dw_min) * BC_PIXB;
+        return __builtin_amdgcn_readlane(lane_off, t);
+    };
+    auto load_a = [&](BFrags<MT, NT>& f, int off) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const unsigned char* ap = halo + lane_base[m] + off;
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(WAVES * 64) void bconv_kernel(const IgemmParams p, 
         // out-of-image pixels load a valid dummy address and are zeroed
         bconv_stage_halo<NTHR>(p, x, halo, cc, n, ih0, iw0, tid);
         __syncthreads();
-        load_a(f0, tap_lo);
+        load_a(f0, tap_off(tap_lo));
+        int off1 = tap_off(tap_lo + 1);                  // offset of the tap after the one in f0
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             auto mma = [&](const BFrags<MT, NT>& f) {
@@ -263,21 +272,26 @@ __global__ __launch_bounds__(WAVES * 64) void bconv_kernel(const IgemmParams p, 
             int t = tb;
             // invariant: f0 holds the operands of tap t
             if (x.dbg & 8) t = te;
+            // every iteration issues the same loads unconditionally (clamped indices): a conditional load makes hipcc
+            // fall back to s_waitcnt vmcnt(0) at the join, i.e. no look-ahead at all
             for (; t + 1 < te; t += 2, seq += 2) {
-                if (!(x.dbg & 2)) load_b(f1, seq + 1);
-                if (!(x.dbg & 4)) load_a(f1, t + 1);
+                const int off2 = tap_off(t + 2);
+                load_b(f1, seq + 1); load_a(f1, off1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(f0);
-                if (!(x.dbg & 2)) load_b(f0, seq + 2);
-                if (!(x.dbg & 4)) load_a(f0, t + 2);
+                const int off3 = tap_off(t + 3);
+                load_b(f0, seq + 2); load_a(f0, off2);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(f1);
+                off1 = off3;
             }
             if (t < te) {                  // odd tap count: one more, then hand the look-ahead set over
-                load_b(f1, seq + 1); load_a(f1, t + 1);
+                const int off2 = tap_off(t + 2);
+                load_b(f1, seq + 1); load_a(f1, off1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(f0);
                 f0 = f1;
+                off1 = off2;
                 ++seq;
             }
         }
