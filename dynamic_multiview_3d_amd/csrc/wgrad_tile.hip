@@ -32,6 +32,7 @@ struct WgTileParams {
     int ntiles_total, tiles_per_slab;
     int b3;              // 1: split-bf16 kernel (wgrad_b3_kernel)
     int inv_hc, tpix8_shift;   // ceil(2^20 / HC); log2(TPIX * 8)
+    int G, img_shift, HRi, inv_hri;   // small images (4x4 feature maps): a tile is G whole images of 2^img_shift pixels, halos stacked
 };
 
 __device__ float4 g_zero16[4];        // 64 bytes of zeros in the code object: source of out-of-image LDS-DMA lanes
@@ -297,17 +298,19 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
         int b = tile;
         const int tw_i = b % p.tiles_w; b /= p.tiles_w;
         const int th_i = b % p.tiles_h;
-        const int n = b / p.tiles_h;
+        const int n = (b / p.tiles_h) * p.G;                 // first image of the tile (G whole images when G > 1)
         const int oh0 = th_i * p.TH, ow0 = tw_i * p.TW;
         const int ih0 = oh0 * p.sh - p.pt, iw0 = ow0 * p.sw - p.pl;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int idx = j * 512 + tid;
             const int pix = idx >> 3, c4 = idx & 7;
-            const int hr = (int)(((unsigned)pix * (unsigned)p.inv_hc) >> 20), hc = pix - hr * p.HC;
+            const int hrt = (int)(((unsigned)pix * (unsigned)p.inv_hc) >> 20), hc = pix - hrt * p.HC;
+            const int gi = p.G > 1 ? (int)(((unsigned)hrt * (unsigned)p.inv_hri) >> 20) : 0;
+            const int hr = hrt - gi * p.HRi;
             const int ih = ih0 + hr, iwc = iw0 + hc, ch = c0 + c4 * 4;
-            const bool ok = idx < n_img4 && (unsigned)ih < (unsigned)p.H && (unsigned)iwc < (unsigned)p.W && ch < p.C;
-            const float* src = ok ? p.img + (int64_t)((n * p.H + ih) * p.W + iwc) * p.img_ld + ch : p.img;
+            const bool ok = idx < n_img4 && n + gi < p.N && (unsigned)ih < (unsigned)p.H && (unsigned)iwc < (unsigned)p.W && ch < p.C;
+            const float* src = ok ? p.img + (int64_t)(((n + gi) * p.H + ih) * p.W + iwc) * p.img_ld + ch : p.img;
             const float4 t4 = *reinterpret_cast<const float4*>(src);
             vi[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -316,9 +319,10 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
             const int idx = j * 512 + tid;
             const int kt = idx >> p.tpix8_shift, rem = idx & ((1 << p.tpix8_shift) - 1);
             const int pq = rem >> 3, c4 = rem & 7;
-            const int oh = oh0 + (pq >> p.tw_shift), ow = ow0 + (pq & (p.TW - 1)), kk = k0 + kt * 32 + c4 * 4;
-            const bool ok = idx < n_feat4 && oh < p.Ho && ow < p.Wo && kk < p.K;
-            const float* src = ok ? p.feat + (int64_t)((n * p.Ho + oh) * p.Wo + ow) * p.feat_ld + kk : p.feat;
+            const int gi = pq >> p.img_shift, pr = pq & ((1 << p.img_shift) - 1);
+            const int oh = oh0 + (pr >> p.tw_shift), ow = ow0 + (pr & (p.TW - 1)), kk = k0 + kt * 32 + c4 * 4;
+            const bool ok = idx < n_feat4 && n + gi < p.N && oh < p.Ho && ow < p.Wo && kk < p.K;
+            const float* src = ok ? p.feat + (int64_t)(((n + gi) * p.Ho + oh) * p.Wo + ow) * p.feat_ld + kk : p.feat;
             const float4 t4 = *reinterpret_cast<const float4*>(src);
             vf[j] = ok ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -369,8 +373,10 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
         for (int s = s_begin; s < s_begin + nsteps; ++s) {
             // pixels of this step handled by this lane as address supplier: 16 s + 8 lh + 4 r + q, r = 0, 1
             const int px0 = 16 * s + 8 * lh + q, px1 = px0 + 4;
-            const int a0 = (((px0 >> p.tw_shift) * p.sh) * p.HC + (px0 & (p.TW - 1))) * 64 + col_bytes;
-            const int a1 = (((px1 >> p.tw_shift) * p.sh) * p.HC + (px1 & (p.TW - 1))) * 64 + col_bytes;
+            const int im = (1 << p.img_shift) - 1;
+            const int r0 = px0 & im, r1 = px1 & im;
+            const int a0 = (((px0 >> p.img_shift) * p.HRi + (r0 >> p.tw_shift) * p.sh) * p.HC + (r0 & (p.TW - 1))) * 64 + col_bytes;
+            const int a1 = (((px1 >> p.img_shift) * p.HRi + (r1 >> p.tw_shift) * p.sh) * p.HC + (r1 & (p.TW - 1))) * 64 + col_bytes;
             const uint2 bh0 = tr_read(fb + px0 * 64), bh1 = tr_read(fb + px1 * 64);
             const uint2 bl0 = tr_read(fb + feat_plane + px0 * 64), bl1 = tr_read(fb + feat_plane + px1 * 64);
             const wbf16x8 bh = __builtin_bit_cast(wbf16x8, make_uint4(bh0.x, bh0.y, bh1.x, bh1.y));
@@ -483,7 +489,10 @@ static int launch_wgb(const WgTileParams& p, dim3 grid, size_t lds, void* stream
 bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out, int* cfg_out, size_t* lds_out) {
     if (disabled_paths() & 2) return false;
     if (g->C < 16 || g->C % 4 != 0 || g->K % 4 != 0 || g->img_ld % 4 != 0 || g->feat_ld % 4 != 0) return false;
-    if (g->Ho * g->Wo < 64 || g->Wo < 8) return false;
+    const bool b3_on = !(disabled_paths() & 4096);
+    // 4x4 feature maps (split-bf16 kernel only): a 128-pixel tile is 8 whole images
+    const bool small = b3_on && g->Ho == 4 && g->Wo == 4 && g->N >= 8;
+    if (!small && (g->Ho * g->Wo < 64 || g->Wo < 8)) return false;
     const int ntaps = g->kh * g->kw;
     // 8 waves = IW item groups x PH pixel ranges; TPW = items per wave (template)
     int NKT, TPW, IW, PH, cfg;
@@ -503,6 +512,19 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     // spatial tile: 128 output pixels (64 if two stride-2 halos do not fit in LDS), least padded work
     int64_t best = -1;
     const size_t xchg = (PH > 1) ? (size_t)IW * TPW * 4096 : 0;            // end-of-kernel partial exchange
+    p.G = 1; p.img_shift = 7; p.HRi = 0;
+    if (small) {
+        for (int G = 8; G >= 4 && best < 0; G >>= 1) {          // 8 images (128 pixels) per tile, 4 when the stride-2 halos are too big
+            const int tpix = G * 16;
+            if ((tpix >> 4) % PH != 0) continue;
+            const int HRi = 3 * g->sh + g->kh, HC = 3 * g->sw + g->kw, HR = G * HRi;
+            const size_t lds = std::max(2 * (size_t)(((HR * HC + tpix * NKT + 7) / 8) * 1024), xchg);
+            if (lds > 160 * 1024 || HR * HC * 8 > 8 * 512) continue;
+            p.G = G; p.img_shift = 4; p.TH = 4; p.TW = 4; p.tw_shift = 2; p.tiles_h = p.tiles_w = 1; p.TPIX = tpix;
+            p.HRi = HRi; p.HC = HC; p.HR = HR;
+            best = 1;
+        }
+    }
     for (int tpix = 128; tpix >= 64 && best < 0; tpix >>= 1) {
         if (b3 ? ((tpix >> 4) % PH != 0) : ((tpix >> 1) / PH < 2)) break;
         for (int sh = 3; sh <= 6; ++sh) {
@@ -528,7 +550,9 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     (void)TPW;
     p.ctiles = cdiv(g->C, 32);
     const int kgroups = cdiv(g->K, 32 * NKT);
-    p.ntiles_total = g->N * p.tiles_h * p.tiles_w;
+    if (p.G == 1) { p.HRi = p.HR; p.img_shift = p.TPIX == 128 ? 7 : 6; }
+    p.inv_hri = ((1 << 20) + p.HRi - 1) / p.HRi;
+    p.ntiles_total = cdiv(g->N, p.G) * p.tiles_h * p.tiles_w;
     // one workgroup per CU in total (operands are prefetched inside the workgroup)
     const int blocks_xy = p.ctiles * kgroups;
     static int wg_cus = -1;

@@ -30,6 +30,8 @@ CONV_CASES = [  # n, h, w, c, k, ksz, s
     (4, 8, 8, 128, 128, 3, 1),       # e3_0 / d4_0
     (4, 8, 8, 128, 256, 3, 2),       # e4
     (8, 4, 4, 256, 256, 3, 1),       # e4_0
+    (8, 8, 8, 128, 256, 3, 2),       # e4 at a batch that packs 4 images per filter-gradient tile
+    (9, 4, 4, 64, 96, 3, 1),         # 4x4 maps, batch not a multiple of the 8 images per tile, 96 filters
     (1, 7, 9, 5, 20, 3, 2),          # ragged: odd sizes, channels not multiples of 4
     (2, 128, 128, 1, 32, 5, 2),      # depth / mask tower e0
     (2, 128, 128, 4, 32, 5, 2),      # 4 input channels (rgb + depth)
