@@ -341,6 +341,96 @@ __global__ __launch_bounds__(256) void smallc_img2feat_kernel(const SmallCParams
     }
 }
 
+
+// Split-bf16 version of the same layer (arithmetic: bconv.hip).  A folded filter row is kw*C <= 16 reduction
+// elements = exactly one v_mfma_f32_32x32x16_bf16 k-step, so a 32-pixel x 32-filter block costs kh * 3 MFMAs instead of
+// kh * ceil(kw*C/2) fp32 ones.  The filter rows are split once per wave into registers and reused over a persistent
+// walk of (image, output row, 32-pixel group) items; a lane's A fragment is 8 consecutive floats of the NHWC input
+// row (4-byte aligned only -- the pitch between output pixels is s*C floats -- hence scalar loads, L1-resident).
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void csplit8(const float (&v)[8], cbf16x8& hi, cbf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(v[j] - (float)h);
+    }
+}
+
+template <int NT, int KH>
+__global__ __launch_bounds__(256) void smallc_b3_kernel(const SmallCParams p, int nitems) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int Cf = p.kw * p.C;                         // <= 16
+    cbf16x8 bh[KH][NT], bl[KH][NT];
+#pragma unroll
+    for (int pr = 0; pr < KH; ++pr)
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+            const int col = y * 32 + li;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = 8 * lh + j;
+                v[j] = (e < Cf && col < p.K && pr < p.kh) ? p.Wt[((int64_t)pr * Cf + e) * p.K + col] : 0.f;
+            }
+            csplit8(v, bh[pr][y], bl[pr][y]);
+        }
+    for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
+        int it = item;
+        const int wt = it % p.wtiles; it /= p.wtiles;
+        const int ho = it % p.Ho;
+        const int n = it / p.Ho;
+        const int wo = wt * 32 + li;
+        const int iw0 = wo * p.sw - p.pl;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+        float a[KH][8];
+#pragma unroll
+        for (int pr = 0; pr < KH; ++pr) {
+            const int ih = ho * p.sh + pr - p.pt;
+            const bool row_ok = pr < p.kh && (unsigned)ih < (unsigned)p.H && wo < p.Wo;
+            const float* xrow = p.X + (int64_t)((n * p.H + (row_ok ? ih : 0)) * p.W) * p.C + (int64_t)iw0 * p.C;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = 8 * lh + j;
+                const int q = e / p.C;
+                const bool ok = row_ok && e < Cf && (unsigned)(iw0 + q) < (unsigned)p.W;
+                const float av = xrow[ok ? e : -(int64_t)iw0 * p.C];        // valid dummy: first element of the row
+                a[pr][j] = ok ? av : 0.f;
+            }
+        }
+#pragma unroll
+        for (int pr = 0; pr < KH; ++pr) {
+            cbf16x8 ah, al;
+            csplit8(a[pr], ah, al);
+#pragma unroll
+            for (int y = 0; y < NT; ++y) {
+                acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pr][y], acc[y], 0, 0, 0);
+                acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pr][y], acc[y], 0, 0, 0);
+                acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pr][y], acc[y], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+            const int col = y * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w2 = wt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (w2 < p.Wo && col < p.K) {
+                    const int64_t pix = (int64_t)(n * p.Ho + ho) * p.Wo + w2;
+                    p.Y[pix * p.y_ld + col] = epilogue_value(p.ep, acc[y][r], pix, col);
+                }
+            }
+        }
+    }
+}
+
 // feat2img with a thin image side (C <= 4: flow field, rgb / depth / mask heads): one thread per
 // output pixel on the VALU, the phase's filter taps staged once per block in LDS.  These layers are
 // HBM/L2-bound (AI ~ 40 flop/B): padding 2 channels to a 32-wide MFMA tile would multiply the work by 16.
@@ -978,7 +1068,12 @@ static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, voi
         const int items = g->N * g->Ho * q.wtiles;
         const bool two = g->K > 32;
         return dispatch(stream, OpInfo{two ? "smallc_img2feat<N64>" : "smallc_img2feat<N32>", conv_flops(g), conv_bytes(g)}, [=](hipStream_t s) {
-            if (two) smallc_img2feat_kernel<2><<<cdiv(items, 4), 256, 0, s>>>(q);
+            const bool b3 = !(disabled_paths() & 4096) && q.kw * q.C <= 16 && (q.kh == 5 || q.kh == 3) && !two;
+            if (b3) {
+                const int blocks = std::min(cdiv(items, 4), 2048);          // persistent walk: the filter split is per wave
+                if (q.kh == 5) smallc_b3_kernel<1, 5><<<blocks, 256, 0, s>>>(q, items);
+                else smallc_b3_kernel<1, 3><<<blocks, 256, 0, s>>>(q, items);
+            } else if (two) smallc_img2feat_kernel<2><<<cdiv(items, 4), 256, 0, s>>>(q);
             else smallc_img2feat_kernel<1><<<cdiv(items, 4), 256, 0, s>>>(q);
             return launched(who);
         });
