@@ -21,6 +21,7 @@
 #include "conv_common.h"
 #include <algorithm>
 #include <mutex>
+#include <string.h>
 #include <vector>
 
 namespace mv3d {
@@ -779,9 +780,9 @@ static const SplitJob* g_table_dev = nullptr;
 static int g_table_jobs = 0, g_total_blocks = 0;
 
 __global__ __launch_bounds__(256) void bconv_split_all_kernel(const SplitJob* __restrict__ jobs, int njobs) {
-    int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;      // block-uniform
-    const SplitJob jb = jobs[j];
+    // block -> job map behind the job array (one dependent load instead of a linear search over ~40 jobs)
+    const int* block_job = reinterpret_cast<const int*>(jobs + njobs);
+    const SplitJob& jb = jobs[block_job[blockIdx.x]];       // read in place: a local copy indexed by `t` would live in scratch
     const int64_t gid = (int64_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
     const int lane = (int)(gid & 63);
     int64_t r = gid >> 6;
@@ -795,10 +796,17 @@ __global__ __launch_bounds__(256) void bconv_split_all_kernel(const SplitJob* __
     const int ch0 = cc * 32 + s * 16 + lh * 8;
     const float* wt = jb.Wt + (int64_t)jb.widx[t] * jb.w_tap_stride;
     float v[8];
+    if (jb.w_ks == 1 && (jb.w_ns & 3) == 0 && ch0 + 8 <= jb.Ka && col < jb.Cc && ((reinterpret_cast<uintptr_t>(wt) & 15) == 0)) {
+        // reduction index contiguous in memory (feature -> image direction): two 16-byte loads per lane
+        const float4* src = reinterpret_cast<const float4*>(wt + (int64_t)col * jb.w_ns + ch0);
+        const float4 u0 = src[0], u1 = src[1];
+        v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int ch = ch0 + e;
-        v[e] = (col < jb.Cc && ch < jb.Ka) ? wt[(int64_t)ch * jb.w_ks + (int64_t)col * jb.w_ns] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+            const int ch = ch0 + e;
+            v[e] = (col < jb.Cc && ch < jb.Ka) ? wt[(int64_t)ch * jb.w_ks + (int64_t)col * jb.w_ns] : 0.f;
+        }
     }
     uint2 h0, l0, h1, l1;
     split4(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
@@ -858,19 +866,30 @@ using namespace mv3d;
 
 extern "C" {
 
+static size_t cache_table_bytes_locked() {
+    size_t blocks = 0;
+    for (const auto& j : g_jobs) blocks += (size_t)j.nblocks;
+    return g_jobs.size() * sizeof(SplitJob) + blocks * sizeof(int);
+}
+
 size_t mv3d_filter_cache_table_bytes(void) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    return g_jobs.size() * sizeof(SplitJob);
+    return cache_table_bytes_locked();
 }
 
 int mv3d_filter_cache_commit(void* table_dev, size_t table_bytes, void* stream) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    const size_t need = g_jobs.size() * sizeof(SplitJob);
+    const size_t need = cache_table_bytes_locked();
     if (g_jobs.empty()) { g_table_dev = nullptr; g_table_jobs = 0; g_total_blocks = 0; return MV3D_OK; }
     if (!table_dev || table_bytes < need) return fail(MV3D_E_INVAL, "mv3d_filter_cache_commit: table %zu < %zu bytes", table_bytes, need);
     int first = 0;
     for (auto& j : g_jobs) { j.first_block = first; first += j.nblocks; }
-    hipError_t e = hipMemcpyAsync(table_dev, g_jobs.data(), need, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
+    std::vector<unsigned char> host(need);
+    memcpy(host.data(), g_jobs.data(), g_jobs.size() * sizeof(SplitJob));
+    int* bj = reinterpret_cast<int*>(host.data() + g_jobs.size() * sizeof(SplitJob));
+    for (size_t i = 0; i < g_jobs.size(); ++i)
+        for (int b = 0; b < g_jobs[i].nblocks; ++b) bj[g_jobs[i].first_block + b] = (int)i;
+    hipError_t e = hipMemcpyAsync(table_dev, host.data(), need, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));      // g_jobs may be edited right after
     if (e != hipSuccess) return fail(MV3D_E_HIP, "mv3d_filter_cache_commit: %s", hipGetErrorString(e));
     g_table_dev = reinterpret_cast<const SplitJob*>(table_dev);
