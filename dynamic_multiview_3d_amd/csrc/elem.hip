@@ -98,6 +98,30 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(const PixelLossParams p
     if (threadIdx.x == 0) atomicAdd(p.loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (p.weight / (float)p.pixels));
 }
 
+// dense, unmasked, unscaled operands (the appearance-flow loss): 16-byte loads / stores over the flat index
+__global__ __launch_bounds__(256) void pixel_loss_dense_kernel(int64_t total4, int64_t pixels, const float4* __restrict__ a,
+                                                              const float4* __restrict__ b, int kind, float weight, float* loss,
+                                                              float4* __restrict__ grad) {
+    const float gscale = (kind == 2 ? 2.0f : 1.0f) * weight / (float)pixels;
+    float sum = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i];
+        const float d[4] = {x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w};
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (kind == 2) { sum += d[e] * d[e]; g[e] = d[e] * gscale; }
+            else { sum += fabsf(d[e]); g[e] = ((d[e] > 0.f) ? 1.f : ((d[e] < 0.f) ? -1.f : 0.f)) * gscale; }
+        }
+        if (grad) grad[i] = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    __shared__ float s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (weight / (float)pixels));
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t count, float v) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) dst[i] = v;
 }
@@ -212,8 +236,21 @@ int mv3d_pixel_loss_strided(int64_t pixels, int ch, const void* a, int a_ld, con
     if (a_ld < ch || b_ld < ch || (grad && grad_ld < ch) || (mask && mask_ld < 1)) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: pixel stride smaller than the channel count");
     PixelLossParams p = {pixels, ch, (const float*)a, a_ld, (const float*)b, b_ld, b_scale, (const float*)mask, mask_ld, kind, weight,
                          (float*)loss_accum, (float*)grad, grad_ld};
-    const int blocks = (int)std::min<int64_t>(cdiv64(pixels * ch, 256 * 8), 1024);
-    return dispatch(stream, OpInfo{"pixel_loss", 0.0, (double)pixels * ch * (grad ? 12.0 : 8.0)}, [=](hipStream_t s) {
+    const int64_t total = pixels * ch;
+    const bool dense = a_ld == ch && b_ld == ch && (!grad || grad_ld == ch) && !mask && b_scale == 1.0f && (total & 3) == 0 &&
+                       ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)grad)) & 15) == 0;
+    if (dense) {
+        const int64_t total4 = total >> 2;
+        // one workgroup per CU: every workgroup ends with an atomic on the single loss word, and those serialise
+        const int blocks4 = (int)std::min<int64_t>(cdiv64(total4, 256 * 2), 256);
+        return dispatch(stream, OpInfo{"pixel_loss", 0.0, (double)total * (grad ? 12.0 : 8.0)}, [=](hipStream_t s) {
+            pixel_loss_dense_kernel<<<blocks4, 256, 0, s>>>(total4, pixels, (const float4*)a, (const float4*)b, kind, weight,
+                                                           (float*)loss_accum, (float4*)grad);
+            return launched("pixel_loss_dense_kernel");
+        });
+    }
+    const int blocks = (int)std::min<int64_t>(cdiv64(total, 256 * 8), 256);
+    return dispatch(stream, OpInfo{"pixel_loss", 0.0, (double)total * (grad ? 12.0 : 8.0)}, [=](hipStream_t s) {
         pixel_loss_kernel<<<blocks, 256, 0, s>>>(p);
         return launched("pixel_loss_kernel");
     });
