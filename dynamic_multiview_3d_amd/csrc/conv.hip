@@ -583,37 +583,65 @@ __global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
     }
 }
 
-// Sums the per-slab partial filters in a fixed order (deterministic).  256 threads = 16 consecutive
-// elements x 16 slab lanes: each thread adds every 16th slab (independent loads in flight), the 16
-// lanes of an element are combined through LDS.
+// Sums the per-slab partial filters in a fixed order (deterministic).  256 threads = 16 element lanes x 16 slab
+// lanes: each thread adds every 16th slab with independent loads in flight, the 16 lanes of an element are combined
+// through LDS.  VEC=4: an element lane owns four consecutive floats (16-byte loads, 256 contiguous bytes per slab row
+// and wave quarter); VEC=1 is the scalar form for counts that are not a multiple of four and for the bias segment.
+template <int VEC>
+__device__ __forceinline__ void reduce_slabs_body(const float* __restrict__ part, int nslab, int64_t count,
+                                                  float* __restrict__ out, int blk, float (*s_sum)[16][17]) {
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = ((int64_t)blk * 16 + e) * VEC;
+    float acc[8][VEC];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[u][v] = 0.f;
+    if (i < count) {
+        const float* p = part + (int64_t)sl * count + i;
+        const int64_t step = 16 * count;
+        int k = sl;
+        for (; k + 112 < nslab; k += 128, p += 8 * step) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if constexpr (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(p + u * step);
+                    acc[u][0] += t.x; acc[u][1] += t.y; acc[u][2] += t.z; acc[u][3] += t.w;
+                } else {
+                    acc[u][0] += p[u * step];
+                }
+            }
+        }
+        for (; k < nslab; k += 16, p += step) {
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                acc[0][0] += t.x; acc[0][1] += t.y; acc[0][2] += t.z; acc[0][3] += t.w;
+            } else {
+                acc[0][0] += p[0];
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+        s_sum[v][sl][e] = ((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v])) + ((acc[4][v] + acc[5][v]) + (acc[6][v] + acc[7][v]));
+    __syncthreads();
+    if (sl < VEC && i < count) {                       // thread (sl = v, e) finishes component v of element lane e
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += s_sum[sl][j][e];
+        out[i + sl] = t;
+    }
+}
+
+template <int VEC>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, int nslab, int64_t count,
                                                           float* __restrict__ out, const float* __restrict__ part2,
                                                           int64_t count2, float* __restrict__ out2, int blocks1) {
     // two segments in one launch: the filter partials and (optionally) the bias partials
-    __shared__ float s_sum[16][17];
-    int blk = blockIdx.x;
-    if (blk >= blocks1) { blk -= blocks1; part = part2; count = count2; out = out2; }
-    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int64_t i = (int64_t)blk * 16 + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (i < count) {
-        int k = sl;
-        for (; k + 48 < nslab; k += 64) {
-            s0 += part[(int64_t)k * count + i];
-            s1 += part[(int64_t)(k + 16) * count + i];
-            s2 += part[(int64_t)(k + 32) * count + i];
-            s3 += part[(int64_t)(k + 48) * count + i];
-        }
-        for (; k < nslab; k += 16) s0 += part[(int64_t)k * count + i];
-    }
-    s_sum[sl][e] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (sl == 0 && i < count) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += s_sum[j][e];
-        out[i] = t;
-    }
+    __shared__ float s_sum[4][16][17];
+    const int blk = blockIdx.x;
+    if (blk >= blocks1) reduce_slabs_body<1>(part2, nslab, count2, out2, blk - blocks1, s_sum);
+    else reduce_slabs_body<VEC>(part, nslab, count, out, blk, s_sum);
 }
 
 
@@ -799,10 +827,12 @@ static bool thin_filtgrad_plan(const mv3d_conv_geom* g, ThinFgParams& p, int* ns
 }
 
 static int dispatch_reduce(void* stream, const float* part, int nslab, int64_t fcount, float* df, const float* bpart, int K, float* db) {
-    const int blocks1 = (int)cdiv64(fcount, 16);
+    const bool vec = fcount % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+    const int blocks1 = (int)cdiv64(fcount, vec ? 64 : 16);
     const int blocks2 = (db && bpart) ? cdiv(K, 16) : 0;
     return dispatch(stream, OpInfo{"reduce_slabs", 0.0, 4.0 * ((double)fcount + (blocks2 ? K : 0)) * (nslab + 1)}, [=](hipStream_t s) {
-        reduce_slabs_kernel<<<blocks1 + blocks2, 256, 0, s>>>(part, nslab, fcount, df, bpart, K, db, blocks1);
+        if (vec) reduce_slabs_kernel<4><<<blocks1 + blocks2, 256, 0, s>>>(part, nslab, fcount, df, bpart, K, db, blocks1);
+        else reduce_slabs_kernel<1><<<blocks1 + blocks2, 256, 0, s>>>(part, nslab, fcount, df, bpart, K, db, blocks1);
         return launched("reduce_slabs_kernel");
     });
 }

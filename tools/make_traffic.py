@@ -42,6 +42,8 @@ LABEL = {
     # both
     'mv3d::adam_kernel': 'adam',
     'mv3d::reduce_slabs_kernel': 'reduce_slabs',
+    'reduce_slabs_kernel<4>': 'reduce_slabs',
+    'reduce_slabs_kernel<1>': 'reduce_slabs/scalar',
     'mv3d::igemm_splitk_epilogue': 'igemm_splitk_epilogue',
     'resample_kernel<false>': 'resample_fwd',
     'resample_kernel<true>': 'resample_bwd',
