@@ -8,24 +8,36 @@ sess.run calls; everything else keeps the reference attribute names.
 import os
 import re
 
+import numpy as np
 import torch
 
+from . import tf_checkpoint
 from .graph import Graph
 
 
 class Saver:
-    """tf.train.Saver stand-in (train.py:70-71,134-136): variables + Adam slots under TF names."""
+    """tf.train.Saver stand-in (train.py:70-71,134-136; mv3d/utils/tf_utils.py:199-212): variables + Adam slots +
+    beta powers under their TF names, written as a TensorFlow V2 checkpoint (`<prefix>.index`,
+    `<prefix>.data-00000-of-00001`, and the `checkpoint` state file next to them) -- see tf_checkpoint.py."""
 
     def __init__(self, graph):
         self.graph = graph
 
-    def save(self, sess, path):
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        torch.save(self.graph.state_dict(), path)
-        return path
+    def save(self, sess, save_path, global_step=None):
+        prefix = save_path if global_step is None else '%s-%d' % (save_path, int(global_step))
+        prefix = os.path.abspath(prefix)
+        tf_checkpoint.write_checkpoint(prefix, {k: v.numpy() for k, v in self.graph.state_dict().items()})
+        tf_checkpoint.update_checkpoint_state(os.path.dirname(prefix), prefix)
+        return prefix
 
-    def restore(self, sess, path):
-        self.graph.load_state_dict(torch.load(path, map_location='cpu'))
+    def restore(self, sess, save_path):
+        if tf_checkpoint.checkpoint_exists(save_path):
+            arrays = tf_checkpoint.read_checkpoint(save_path)
+            self.graph.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in arrays.items()})
+        elif os.path.isfile(save_path):                      # state dict written by torch.save (pre-bundle snapshots)
+            self.graph.load_state_dict(torch.load(save_path, map_location='cpu'))
+        else:
+            raise FileNotFoundError("no checkpoint at %r (expected %s.index)" % (save_path, save_path))
 
 
 class AdamOptimizer:

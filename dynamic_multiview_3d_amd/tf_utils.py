@@ -320,3 +320,25 @@ def tile_spatial(code, h, w):
     code.grad_consumers += 1
     out.producer = g.add(TileNode(code, out, h * w))
     return out
+
+
+# ---------------------------------------------------------------------------- snapshots (mv3d/utils/tf_utils.py:199-212)
+def save_snapshot(saver, session, path, step):
+    """saver.save(session, path/snapshot<step>, global_step=step): files `snapshot<step>-<step>.index|.data-*`."""
+    import os
+    return saver.save(session, os.path.join(path, "snapshot" + str(step)), global_step=step)
+
+
+def load_snapshot(saver, session, path):
+    """Restore the checkpoint the `checkpoint` state file of `path` names; returns its iteration (the digits after
+    the last '-'), or None when the directory holds no checkpoint state."""
+    import re
+    from . import tf_checkpoint
+    ckpt = tf_checkpoint.get_checkpoint_state(path)
+    if ckpt is None:
+        return None
+    print("loading " + ckpt['model_checkpoint_path'] + "...")
+    saver.restore(session, ckpt['model_checkpoint_path'])
+    num_iter = int(re.match(r'.*-(\d*)$', ckpt['model_checkpoint_path']).group(1))
+    print("done.")
+    return num_iter

@@ -4,12 +4,14 @@ Same flags (--hyper, --visualize, --device, --pretrained), same conf files (a py
 `configuration` dict; reference-style confs that `from appearance_flow_model import ...` load
 unchanged), same model selection (conf['model'], default Base_Prediction_Model: train.py:57-60), same
 loop cadence (iterations itr_0..num_iterations inclusive, log every 10, validation every 500,
-checkpoint every 10 000 to output_dir/model<itr>, resume iteration parsed from the checkpoint name:
-train.py:95-103,117-154).  sess.run([loss, train_op]) is model.train_step().
+checkpoint every 10 000 to output_dir/model<itr> as a TensorFlow V2 bundle (tf_checkpoint.py), resume iteration
+parsed from the checkpoint name: train.py:95-103,117-154).  sess.run([loss, train_op]) is model.train_step().
+
+Input: the TFRecord shards under conf['data_dir'] (read_tf_records.py); when that directory holds no files, or with
+--synthetic, seeded synthetic batches shaped like the reader's tensors.
 
 Not ported: TF summaries (a JSON-lines log is written instead), --visualize (matplotlib plotting,
-SURVEY 2 #14, out of scope).  The TFRecord reader is a later row; until it exists the
-driver feeds seeded synthetic batches shaped like the reader's tensors.
+SURVEY 2 #14, out of scope).
 """
 import argparse
 import importlib

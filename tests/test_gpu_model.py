@@ -231,16 +231,19 @@ def test_train_driver_runs_saves_and_resumes(tmp_path):
         "  'num_iterations': 30, 'batch_size': 2, 'learning_rate': 1e-4, 'train_val_split': 0.95, 'model': AppFlowLowDimAngle}\n")
     model = train.main(['--hyper', str(conf_py)])
     out = tmp_path / 'modeldata'
-    assert (out / 'model').exists()
+    assert (out / 'model.index').exists() and (out / 'model.data-00000-of-00001').exists() and (out / 'checkpoint').exists()
     import json
     rows = [json.loads(l) for l in open(out / 'train_log.jsonl')]
     its = [r['itr'] for r in rows if 'training_loss' in r]
     assert its == [0, 10, 20, 30]                                                  # range(itr_0, num_iterations + 1)
     losses = [r['training_loss'] for r in rows if 'training_loss' in r]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
-    sd = torch.load(out / 'model', map_location='cpu')
+    from dynamic_multiview_3d_amd import tf_checkpoint
+    sd = tf_checkpoint.read_checkpoint(str(out / 'model'))
     assert 'a0/Matrix/Adam_1' in sd and abs(float(sd['beta1_power']) - 0.9 ** 32) < 1e-6      # 31 steps taken
-    os.replace(out / 'model', out / 'model30')
+    assert tf_checkpoint.get_checkpoint_state(str(out))['model_checkpoint_path'] == str(out / 'model')
+    for ext in ('.index', '.data-00000-of-00001'):
+        os.replace(str(out / 'model') + ext, str(out / 'model30') + ext)
     model2 = train.main(['--hyper', str(conf_py), '--pretrained', str(out / 'model30'), '--num_iterations', '33'])
     rows = [json.loads(l) for l in open(out / 'train_log.jsonl')]
     assert [r['itr'] for r in rows if 'training_loss' in r][-1] == 30              # resumed at 30: logs itr 30 again
