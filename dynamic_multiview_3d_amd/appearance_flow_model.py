@@ -84,3 +84,8 @@ class AppearanceFlowModel(ModelBase):
         self.flow_field = deconv2d_msra(d1_0, [self.batch_size, 128, 128, 2], 5, 5, 2, 2, "flow_field")
         self.warp_pts = warp_pts_layer(self.flow_field)
         self.gen = resample_layer(image0, self.warp_pts)
+
+    def visualize(self, sess=None, **feeds):
+        """One forward pass, then the reference's qualitative outputs (visualize.py)."""
+        from . import visualize as _v
+        return _v.visualize_appearance_flow(self, sess, **feeds)

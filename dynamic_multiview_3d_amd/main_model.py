@@ -110,3 +110,8 @@ class Base_Prediction_Model(ModelBase):
         if 'use_depth' in self.conf:
             self.loss += euclidean_loss(self.gen_dimage1, self.dimage1) * self.conf['depth_lr_factor']
         self.train_op = AdamOptimizer(self.conf['learning_rate']).minimize(self.loss, self.graph)
+
+    def visualize(self, sess=None, **feeds):
+        """One forward pass, then the reference's qualitative outputs (visualize.py)."""
+        from . import visualize as _v
+        return _v.visualize_prediction(self, sess, **feeds)

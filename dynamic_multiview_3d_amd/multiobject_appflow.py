@@ -194,3 +194,8 @@ class MultiObjectAppFlow(ModelBase):
             self.loss += mask_loss
 
         self.train_op = AdamOptimizer(self.conf['learning_rate']).minimize(self.loss, self.graph)
+
+    def visualize(self, sess=None, **feeds):
+        """One forward pass, then the reference's qualitative outputs (visualize.py)."""
+        from . import visualize as _v
+        return _v.visualize_multiobject(self, sess, **feeds)

@@ -342,3 +342,6 @@ def load_snapshot(saver, session, path):
     num_iter = int(re.match(r'.*-(\d*)$', ckpt['model_checkpoint_path']).group(1))
     print("done.")
     return num_iter
+
+
+from .visualize import save_images, rescale_image, rescale_dm      # noqa: E402,F401  (tf_utils.py:101-147)

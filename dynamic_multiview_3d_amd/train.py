@@ -10,8 +10,8 @@ parsed from the checkpoint name: train.py:95-103,117-154).  sess.run([loss, trai
 Input: the TFRecord shards under conf['data_dir'] (read_tf_records.py); when that directory holds no files, or with
 --synthetic, seeded synthetic batches shaped like the reader's tensors.
 
-Not ported: TF summaries (a JSON-lines log is written instead), --visualize (matplotlib plotting,
-SURVEY 2 #14, out of scope).
+--visualize <checkpoint name> restores output_dir/<name> and writes the model's qualitative outputs (visualize.py).
+Not ported: TF summaries (a JSON-lines log is written instead).
 """
 import argparse
 import importlib
@@ -104,7 +104,7 @@ class SyntheticData:
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
     ap.add_argument('--hyper', default='../../tensorflowdata/appflow_offset/conf.py', help='hyperparameters configuration file')
-    ap.add_argument('--visualize', default='', help='(not ported) model within hyperparameter folder from which to create gifs')
+    ap.add_argument('--visualize', default='', help='model within hyperparameter folder from which to create gifs')
     ap.add_argument('--device', default='0', help='GPU index (the reference sets CUDA_VISIBLE_DEVICES)')
     ap.add_argument('--pretrained', default=None, help='path to model file from which to resume training')
     ap.add_argument('--num_iterations', type=int, default=None, help='override conf["num_iterations"]')
@@ -112,8 +112,13 @@ def main(argv=None):
     FLAGS = ap.parse_args(argv)
 
     conf = load_conf(FLAGS.hyper)
-    if FLAGS.visualize:
-        sys.exit("--visualize is not ported (matplotlib plotting is outside the hot path)")
+    if FLAGS.visualize:                                               # train.py:47-55
+        print('creating visualizations ...')
+        conf['data_dir'] = '/'.join(str.split(conf.get('data_dir') or '', '/')[:-1] + ['test'])
+        conf['visualize'] = conf['output_dir'] + '/' + FLAGS.visualize
+        conf['event_log_dir'] = '/tmp'
+        conf['batch_size'] = 10
+        conf['test_mode'] = ''
     if FLAGS.num_iterations is not None:
         conf['num_iterations'] = FLAGS.num_iterations
 
@@ -123,7 +128,7 @@ def main(argv=None):
     torch.cuda.set_device(torch.device(dev))
 
     Model = select_model(conf)
-    model = Model(conf, load_tfrec=True, build_loss=True, device=dev)
+    model = Model(conf, load_tfrec=True, build_loss=not FLAGS.visualize, device=dev)
     if world > 1:
         model.enable_data_parallel(world)
     saver = model.saver
@@ -140,6 +145,17 @@ def main(argv=None):
             print('no TFRecord shards at conf["data_dir"] = %r: training on synthetic batches' % (data_dir,))
         train_data = SyntheticData(model, seed=rank)
         val_data = SyntheticData(model, seed=10_000 + rank, pool=1)
+
+    if FLAGS.visualize:                                               # train.py:80-92
+        print('-------------------------------------------------------------------')
+        print('verify current settings!! ')
+        for key in conf.keys():
+            print(key, ': ', conf[key])
+        print('-------------------------------------------------------------------')
+        saver.restore(None, conf['visualize'])
+        print('restore done.')
+        model.visualize(None, **train_data.next())
+        return model
 
     itr_0 = 0
     if FLAGS.pretrained is not None:
