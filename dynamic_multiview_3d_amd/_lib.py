@@ -50,6 +50,7 @@ STATUS_FUNCS = {
     "mv3d_group_sum": [_i64, _i, _i, _vp, _i64, _vp, _i64, _vp],
     "mv3d_warp_resample_fwd": [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "mv3d_warp_resample_bwd": [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
+    "mv3d_warp_resample_loss": [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp],
     "mv3d_pixel_loss": [_i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "mv3d_pixel_loss_strided": [_i64, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _f, _vp, _vp, _i, _vp],
     "mv3d_fill": [_vp, _i64, _f, _vp],

@@ -3,6 +3,7 @@
 // fp32 expressions round exactly like the reference's unfused TF kernels (and the numpy oracle).
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace mv3d {
 
@@ -18,8 +19,13 @@ struct ResampleParams {
     int N, H, W, Hs, Ws, C, flow_ld, dflow_ld;
 };
 
+// One bilinear tap.  The load is unconditional from a clamped (always valid) address and the bounds test only
+// selects the result: a load under a branch makes hipcc wait for it at the join, i.e. one memory round trip per tap.
 __device__ __forceinline__ float tap(const float* img, int Ws, int Hs, int C, int y, int x, int c) {
-    return ((unsigned)x < (unsigned)Ws && (unsigned)y < (unsigned)Hs) ? img[((int64_t)y * Ws + x) * C + c] : 0.f;
+    const bool ok = (unsigned)x < (unsigned)Ws && (unsigned)y < (unsigned)Hs;
+    const int xc = min(max(x, 0), Ws - 1), yc = min(max(y, 0), Hs - 1);
+    const float v = img[((int64_t)yc * Ws + xc) * C + c];
+    return ok ? v : 0.f;
 }
 
 template <bool BWD>
@@ -62,6 +68,164 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleParams p) {
         float* d = p.dflow + pix * p.dflow_ld;
         d[0] = gx; d[1] = gy;
     }
+}
+
+// Tiled form of the same arithmetic.  The coords quirk makes the sampler read the TRANSPOSED neighbourhood of an output
+// pixel (source row ~ j, source column ~ i), so with one thread per output pixel in row-major order every gather
+// instruction touches 32-64 different cache lines and the kernel is bound by the texture-address unit (~25 us for
+// 33 MB).  Here a workgroup owns a 32 x 32 output tile and goes through LDS twice:
+//   A (j fastest)  coalesced reads of flow (+ target / incoming gradient) -> LDS, warp_pts written
+//   B (i fastest)  lanes run along source rows: the four taps of 32 consecutive lanes are (nearly) contiguous;
+//                  gen, the loss term and the flow gradient are computed here with the expressions of resample_kernel
+//   C (j fastest)  coalesced stores of gen / dflow from LDS
+// MODE 0 = forward, 1 = gradient w.r.t. flow from a given dgen, 2 = forward + pixel loss against `tgt` + gradient in one
+// pass (the appearance-flow head: gen is only consumed by the loss, so dgen never needs to exist in HBM).
+struct ResampleTileParams {
+    const float* src; const float* flow; const float* aux;     // aux: dgen (MODE 1) or target (MODE 2), pixel stride aux_ld
+    float* warp; float* gen; float* dflow; float* loss;
+    int N, H, W, Hs, Ws, flow_ld, aux_ld, dflow_ld, kind;
+    float weight;
+    int tiles_i, tiles_j, n_tiles;
+};
+
+template <int MODE, int C>
+__global__ __launch_bounds__(256) void resample_tile_kernel(const ResampleTileParams p) {
+    constexpr int P = 33;                                   // LDS pitch: transposed reads hit 32 different banks
+    __shared__ float s_xy[2][32 * P];                       // x, y; then gx, gy
+    __shared__ float s_c[C][32 * P];                        // target / dgen; then gen
+    const int lo = threadIdx.x & 31, hi = threadIdx.x >> 5;
+    const float inv_pix = 1.0f / (float)((int64_t)p.N * p.H * p.W);
+    const float gscale = (p.kind == 2 ? 2.0f : 1.0f) * p.weight / (float)((int64_t)p.N * p.H * p.W);
+    float sum = 0.f;
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        int b = tile;
+        const int tj = b % p.tiles_j; b /= p.tiles_j;
+        const int ti = b % p.tiles_i;
+        const int n = b / p.tiles_i;
+        const int i0 = ti * 32, j0 = tj * 32;
+        const float* img = p.src + (int64_t)n * p.Hs * p.Ws * C;
+        // ---- A: all loads first (clamped indices, no branches), then the LDS writes
+        {
+            float fx_[4], fy_[4], av[4][C];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(i0 + hi + 8 * k, p.H - 1), j = min(j0 + lo, p.W - 1);
+                const int64_t pix = ((int64_t)n * p.H + i) * p.W + j;
+                const float* fl = p.flow + pix * p.flow_ld;
+                fx_[k] = fl[0]; fy_[k] = fl[1];
+                if (MODE != 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) av[k][c] = p.aux[pix * p.aux_ld + c];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = hi + 8 * k, i = i0 + r, j = j0 + lo;
+                const float x = fx_[k] + (float)min(i, p.H - 1), y = fy_[k] + (float)min(j, p.W - 1);
+                s_xy[0][r * P + lo] = x; s_xy[1][r * P + lo] = y;
+                if (MODE != 0) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) s_c[c][r * P + lo] = av[k][c];
+                }
+                if (MODE != 1 && p.warp && i < p.H && j < p.W) {
+                    const int64_t pix = ((int64_t)n * p.H + i) * p.W + j;
+                    p.warp[pix * 2] = x; p.warp[pix * 2 + 1] = y;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- B: the 4 x 4 x C taps of a thread's four pixels are requested before any of them is used
+        {
+            float tp[4][4][C];          // [pixel][ff, cc, fc, cf][channel]
+            float dxs[4], dys[4];
+            bool vld[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = hi + 8 * k;
+                const float x = s_xy[0][lo * P + q], y = s_xy[1][lo * P + q];
+                vld[k] = x > -1.0f && y > -1.0f && x < (float)p.Ws && y < (float)p.Hs;
+                const float fxf = floorf(x), fyf = floorf(y);
+                // the clamp keeps the int conversion defined for far-away / non-finite sample points (they are not valid)
+                const int fx = (int)fminf(fmaxf(fxf, -2.0f), (float)p.Ws), fy = (int)fminf(fmaxf(fyf, -2.0f), (float)p.Hs);
+                const int cx = fx + 1, cy = fy + 1;
+                dxs[k] = (fxf + 1.0f) - x; dys[k] = (fyf + 1.0f) - y;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    tp[k][0][c] = tap(img, p.Ws, p.Hs, C, fy, fx, c); tp[k][1][c] = tap(img, p.Ws, p.Hs, C, cy, cx, c);
+                    tp[k][2][c] = tap(img, p.Ws, p.Hs, C, cy, fx, c); tp[k][3][c] = tap(img, p.Ws, p.Hs, C, fy, cx, c);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = lo, q = hi + 8 * k;
+                const bool inr = i0 + r < p.H && j0 + q < p.W;
+                const bool valid = vld[k];
+                const float dx = dxs[k], dy = dys[k];
+                float gx = 0.f, gy = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float iff = valid ? tp[k][0][c] : 0.f, icc = valid ? tp[k][1][c] : 0.f;
+                    const float ifc = valid ? tp[k][2][c] : 0.f, icf = valid ? tp[k][3][c] : 0.f;
+                    float g = 0.f;
+                    if (MODE != 1) {
+                        const float v = valid ? ((dx * dy * iff + (1.0f - dx) * (1.0f - dy) * icc) + dx * (1.0f - dy) * ifc) + (1.0f - dx) * dy * icf : 0.f;
+                        if (MODE == 2) {
+                            const float d = v - s_c[c][r * P + q];
+                            if (p.kind == 2) { sum += inr ? d * d : 0.f; g = d * gscale; }
+                            else { sum += inr ? fabsf(d) : 0.f; g = ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) * gscale; }
+                        }
+                        s_c[c][r * P + q] = v;
+                    } else {
+                        g = s_c[c][r * P + q];
+                    }
+                    if (MODE != 0) {
+                        const float tx = g * (dy * (icf - iff) + (1.0f - dy) * (icc - ifc));
+                        const float ty = g * (dx * (ifc - iff) + (1.0f - dx) * (icc - icf));
+                        gx += valid ? tx : 0.f;
+                        gy += valid ? ty : 0.f;
+                    }
+                }
+                if (MODE != 0) { s_xy[0][r * P + q] = gx; s_xy[1][r * P + q] = gy; }
+            }
+        }
+        __syncthreads();
+        // ---- C
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = hi + 8 * k, i = i0 + r, j = j0 + lo;
+            if (i < p.H && j < p.W) {
+                const int64_t pix = ((int64_t)n * p.H + i) * p.W + j;
+                if (MODE != 1) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) p.gen[pix * C + c] = s_c[c][r * P + lo];
+                }
+                if (MODE != 0 && p.dflow) { p.dflow[pix * p.dflow_ld] = s_xy[0][r * P + lo]; p.dflow[pix * p.dflow_ld + 1] = s_xy[1][r * P + lo]; }
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == 2) {
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+        if ((threadIdx.x & 63) == 0) s_xy[0][threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(p.loss, (s_xy[0][0] + s_xy[0][1] + s_xy[0][2] + s_xy[0][3]) * (p.weight * inv_pix));
+    }
+}
+
+template <int MODE>
+static void launch_resample_tile(const ResampleTileParams& p, int C, int blocks, hipStream_t s) {
+    switch (C) {
+        case 1: resample_tile_kernel<MODE, 1><<<blocks, 256, 0, s>>>(p); break;
+        case 2: resample_tile_kernel<MODE, 2><<<blocks, 256, 0, s>>>(p); break;
+        case 3: resample_tile_kernel<MODE, 3><<<blocks, 256, 0, s>>>(p); break;
+        default: resample_tile_kernel<MODE, 4><<<blocks, 256, 0, s>>>(p); break;
+    }
+}
+
+static int resample_tile_blocks(ResampleTileParams& p) {
+    p.tiles_i = cdiv(p.H, 32); p.tiles_j = cdiv(p.W, 32);
+    p.n_tiles = p.N * p.tiles_i * p.tiles_j;
+    return std::min(p.n_tiles, 1024);          // MODE 2 ends in one atomic per workgroup: keep that count small
 }
 
 // ---------------------------------------------------------------- pixel losses (tf_utils.py:18-23)
@@ -207,6 +371,16 @@ int mv3d_warp_resample_fwd(int N, int H, int W, int Hs, int Ws, int C, const voi
     if (N <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || flow_ld < 2) return fail(MV3D_E_INVAL, "mv3d_warp_resample_fwd: bad shape");
     if (!src || !flow || !gen) return fail(MV3D_E_INVAL, "mv3d_warp_resample_fwd: null pointer");
     if (N > 65535) return fail(MV3D_E_UNSUPPORTED, "mv3d_warp_resample_fwd: batch > 65535");
+    if (C <= 4 && !(disabled_paths() & 65536)) {
+        ResampleTileParams t = {};
+        t.src = (const float*)src; t.flow = (const float*)flow; t.warp = (float*)warp_out; t.gen = (float*)gen;
+        t.N = N; t.H = H; t.W = W; t.Hs = Hs; t.Ws = Ws; t.flow_ld = flow_ld;
+        const int blocks = resample_tile_blocks(t);
+        return dispatch(stream, OpInfo{"resample_fwd", 0.0, (double)N * H * W * (8.0 + 8.0 * C)}, [=](hipStream_t s) {
+            launch_resample_tile<0>(t, C, blocks, s);
+            return launched("resample_tile_kernel<fwd>");
+        });
+    }
     ResampleParams p = {(const float*)src, (const float*)flow, nullptr, (float*)warp_out, (float*)gen, nullptr, N, H, W, Hs, Ws, C, flow_ld, 0};
     dim3 grid(cdiv(W, 32), cdiv(H, 8), N);
     return dispatch(stream, OpInfo{"resample_fwd", 0.0, (double)N * H * W * (8.0 + 8.0 * C)}, [=](hipStream_t s) {
@@ -220,11 +394,41 @@ int mv3d_warp_resample_bwd(int N, int H, int W, int Hs, int Ws, int C, const voi
     if (N <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || flow_ld < 2 || dflow_ld < 2) return fail(MV3D_E_INVAL, "mv3d_warp_resample_bwd: bad shape");
     if (!src || !flow || !dgen || !dflow) return fail(MV3D_E_INVAL, "mv3d_warp_resample_bwd: null pointer");
     if (N > 65535) return fail(MV3D_E_UNSUPPORTED, "mv3d_warp_resample_bwd: batch > 65535");
+    if (C <= 4 && !(disabled_paths() & 65536)) {
+        ResampleTileParams t = {};
+        t.src = (const float*)src; t.flow = (const float*)flow; t.aux = (const float*)dgen; t.aux_ld = C; t.dflow = (float*)dflow;
+        t.N = N; t.H = H; t.W = W; t.Hs = Hs; t.Ws = Ws; t.flow_ld = flow_ld; t.dflow_ld = dflow_ld;
+        const int blocks = resample_tile_blocks(t);
+        return dispatch(stream, OpInfo{"resample_bwd", 0.0, (double)N * H * W * (16.0 + 8.0 * C)}, [=](hipStream_t s) {
+            launch_resample_tile<1>(t, C, blocks, s);
+            return launched("resample_tile_kernel<bwd>");
+        });
+    }
     ResampleParams p = {(const float*)src, (const float*)flow, (const float*)dgen, nullptr, nullptr, (float*)dflow, N, H, W, Hs, Ws, C, flow_ld, dflow_ld};
     dim3 grid(cdiv(W, 32), cdiv(H, 8), N);
     return dispatch(stream, OpInfo{"resample_bwd", 0.0, (double)N * H * W * (16.0 + 8.0 * C)}, [=](hipStream_t s) {
         resample_kernel<true><<<grid, 256, 0, s>>>(p);
         return launched("resample_kernel<bwd>");
+    });
+}
+
+int mv3d_warp_resample_loss(int N, int H, int W, int Hs, int Ws, int C, const void* src, const void* flow, int flow_ld,
+                            const void* target, int target_ld, int kind, float weight, void* warp_out, void* gen,
+                            void* dflow, int dflow_ld, void* loss_accum, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || flow_ld < 2 || target_ld < C || (dflow && dflow_ld < 2))
+        return fail(MV3D_E_INVAL, "mv3d_warp_resample_loss: bad shape");
+    if (kind != 1 && kind != 2) return fail(MV3D_E_INVAL, "mv3d_warp_resample_loss: kind must be 1 (l1) or 2 (euclidean)");
+    if (!src || !flow || !target || !gen || !loss_accum) return fail(MV3D_E_INVAL, "mv3d_warp_resample_loss: null pointer");
+    if (C > 4) return fail(MV3D_E_UNSUPPORTED, "mv3d_warp_resample_loss: more than 4 channels");
+    ResampleTileParams t = {};
+    t.src = (const float*)src; t.flow = (const float*)flow; t.aux = (const float*)target; t.aux_ld = target_ld;
+    t.warp = (float*)warp_out; t.gen = (float*)gen; t.dflow = (float*)dflow; t.loss = (float*)loss_accum;
+    t.N = N; t.H = H; t.W = W; t.Hs = Hs; t.Ws = Ws; t.flow_ld = flow_ld; t.dflow_ld = dflow_ld; t.kind = kind; t.weight = weight;
+    static const int max_blocks = getenv("MV3D_RL_BLOCKS") ? atoi(getenv("MV3D_RL_BLOCKS")) : 512;
+    const int blocks = std::min(resample_tile_blocks(t), max_blocks);
+    return dispatch(stream, OpInfo{"resample_loss", 0.0, (double)N * H * W * (8.0 + 8.0 + 8.0 + 12.0 * C)}, [=](hipStream_t s) {
+        launch_resample_tile<2>(t, C, blocks, s);
+        return launched("resample_tile_kernel<fused>");
     });
 }
 

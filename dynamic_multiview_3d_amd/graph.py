@@ -397,15 +397,26 @@ class ResampleNode(Node):
 
     def __init__(self, src, flow, warp, gen):
         self.src, self.flow, self.warp, self.gen = src, flow, warp, gen
+        self.fused_loss = None      # (weight, LossTerm) when gen feeds exactly one plain pixel loss (Graph._fuse_resample_losses)
 
     def forward(self, g):
         n, h, w, _ = self.flow.shape
         _, hs, ws, c = self.src.shape
+        if self.fused_loss is not None:
+            # sampler + loss + sampler gradient in one pass: the loss gradient d(gen) never goes to HBM
+            wgt, term = self.fused_loss
+            want_grad = self.flow.requires_grad
+            g.lib.warp_resample_loss(n, h, w, hs, ws, c, self.src.ptr, self.flow.ptr, self.flow.ld, term.b.ptr, term.b.ld,
+                                     term.kind, float(wgt), self.warp.ptr, self.gen.ptr,
+                                     self.flow.grad_ptr if want_grad else None, self.flow.ld, g.loss_buf.data_ptr(), g.stream)
+            if want_grad:
+                _note_grad_written(self.flow, False)
+            return
         g.lib.warp_resample_fwd(n, h, w, hs, ws, c, self.src.ptr, self.flow.ptr, self.flow.ld,
                                 self.warp.ptr, self.gen.ptr, g.stream)
 
     def backward(self, g):
-        if not self.gen.grad_written or not self.flow.requires_grad:
+        if self.fused_loss is not None or not self.gen.grad_written or not self.flow.requires_grad:
             return
         n, h, w, _ = self.flow.shape
         _, hs, ws, c = self.src.shape
@@ -538,11 +549,46 @@ class Graph:
         self.ws_side = [torch.empty(max(need // 4, 4), dtype=torch.float32, device=dev) for _ in range(self.n_side)]
 
     # ---------------------------------------------------------------- plans
+    def _fuse_resample_losses(self):
+        """A resampler output that is consumed by exactly one unmasked, unscaled pixel loss and by no other node (the
+        appearance-flow head, appearance_flow_model.py:127-130 + build_loss) is computed together with that loss and
+        the flow gradient by mv3d_warp_resample_loss.  MV3D_FUSE_RESAMPLE=0 keeps the three separate launches."""
+        self.fused_terms = set()
+        enabled = os.environ.get('MV3D_FUSE_RESAMPLE', '1') != '0'
+        for n in self.nodes:
+            if not isinstance(n, ResampleNode):
+                continue
+            n.fused_loss = None
+            if not enabled or self.loss_expr is None:
+                continue
+            gen = n.gen
+            uses = [(w, t) for w, t in self.loss_expr.terms if t.a is gen or t.b is gen or t.mask is gen]
+            if len(uses) != 1:
+                continue
+            w, t = uses[0]
+            if t.a is not gen or t.mask is not None or t.b_scale != 1.0 or t.b.requires_grad or t.b.rows != gen.rows or t.b.C != gen.C:
+                continue
+            if gen.C > 4 or gen.ld != gen.C or gen.storage.has_alias or gen.storage.alias_of is not None:
+                continue
+            read_elsewhere = False
+            for m in self.nodes:
+                if m is n:
+                    continue
+                for v in vars(m).values():
+                    vs = v if isinstance(v, (list, tuple)) else (v,)
+                    if any(x is gen for x in vs):
+                        read_elsewhere = True
+            if read_elsewhere:
+                continue
+            n.fused_loss = (w, t)
+            self.fused_terms.add(id(t))
+
     def _emit_losses(self, with_grad):
-        self.lib.fill(self.loss_buf.data_ptr(), 1, 0.0, self.stream)
         if self.loss_expr is None:
             return
         for w, term in self.loss_expr.terms:
+            if id(term) in self.fused_terms:
+                continue
             a, b, m = term.a, term.b, term.mask
             if a.C != b.C or a.rows != b.rows:
                 raise ValueError("loss operands of different shapes")
@@ -561,10 +607,12 @@ class Graph:
         for t in self.tensors:
             t.grad_written = t.grad_masked = False
         self._bind_prepared_filters()
+        self._fuse_resample_losses()
         self.plan_fwd = lib.plan_create()
         lib.plan_begin(self.plan_fwd)
         try:
             lib.filter_cache_refresh(None)      # first launch of the step: convert every conv filter once
+            lib.fill(self.loss_buf.data_ptr(), 1, 0.0, self.stream)      # loss terms accumulate into loss_buf[0]
             for n in self.nodes:
                 n.forward(self)
             self._emit_losses(with_grad=True)

@@ -146,6 +146,13 @@ int mv3d_warp_resample_fwd(int N, int H, int W, int Hs, int Ws, int C, const voi
 /* dflow[N,H,W,2] (pixel stride dflow_ld) = resampler grad w.r.t. warp (= grad w.r.t. flow) */
 int mv3d_warp_resample_bwd(int N, int H, int W, int Hs, int Ws, int C, const void* src, const void* flow, int flow_ld,
                            const void* dgen, void* dflow, int dflow_ld, void* stream);
+/* The appearance-flow head in one pass (appearance_flow_model.py:127-130 + tf_utils.py:18-23): gen = resample(src, flow +
+ * coords); loss_accum[0] += weight * mean_{n,h,w} sum_c f(gen - target) (kind 2 squared, 1 absolute); dflow (optional) =
+ * d(weight * loss)/dflow.  Same arithmetic as mv3d_warp_resample_fwd -> mv3d_pixel_loss -> mv3d_warp_resample_bwd with the
+ * loss gradient kept on chip.  target [N,H,W,C] with pixel stride target_ld; C <= 4. */
+int mv3d_warp_resample_loss(int N, int H, int W, int Hs, int Ws, int C, const void* src, const void* flow, int flow_ld,
+                            const void* target, int target_ld, int kind, float weight, void* warp_out, void* gen,
+                            void* dflow, int dflow_ld, void* loss_accum, void* stream);
 
 /* ---- losses: euclidean_loss / l1_loss (tf_utils.py:18-23) -----------------------------------
  * loss_accum[0] += weight * mean_{n,h,w} sum_c f((a-b)*mask);  grad (optional, same shape as a,

@@ -232,6 +232,71 @@ def test_resampler_fwd_bwd_random_and_edges():
     np.testing.assert_allclose(host(dflow), rdw, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("n,h,w,hs,ws_,c", [(2, 40, 72, 40, 72, 3), (1, 33, 31, 33, 31, 1), (3, 64, 64, 64, 64, 4), (1, 16, 16, 24, 20, 2)])
+def test_resampler_tiles_ragged_sizes(n, h, w, hs, ws_, c):
+    """The 32 x 32 tile kernels on sizes that are not tile multiples, non-square outputs and sources of another size."""
+    src = RNG.standard_normal((n, hs, ws_, c)).astype(np.float32)
+    flow = RNG.uniform(-9, 9, (n, h, w, 2)).astype(np.float32)
+    flow[0, :2, :3] = 0.0
+    warp, gen, ds, df = _resample(src, flow)
+    rwarp = ops.warp_pts_layer(flow)
+    np.testing.assert_array_equal(warp, rwarp)
+    np.testing.assert_allclose(gen, ops.resampler_fwd(src, rwarp), rtol=0, atol=2e-6)
+    g = RNG.standard_normal(gen.shape).astype(np.float32)
+    dg = dev(g)
+    dflow = torch.full((n, h, w, 2), float('nan'), device='cuda')
+    L().warp_resample_bwd(n, h, w, hs, ws_, c, ds.data_ptr(), df.data_ptr(), 2, dg.data_ptr(), dflow.data_ptr(), 2, stream())
+    _, rdw = ops.resampler_bwd(src, rwarp, g, need_ddata=False)
+    np.testing.assert_allclose(host(dflow), rdw, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", [2, 1])
+@pytest.mark.parametrize("n,h,c", [(2, 128, 3), (3, 40, 3), (1, 32, 1), (2, 48, 4)])
+def test_fused_resample_loss_matches_the_three_separate_ops(kind, n, h, c):
+    """mv3d_warp_resample_loss = resampler -> pixel loss -> resampler gradient (oracle functions), with the loss
+    gradient never stored: outputs, loss and flow gradient; also against the library's own separate launches."""
+    src = RNG.uniform(0, 1, (n, h, h, c)).astype(np.float32)
+    tgt = RNG.uniform(0, 1, (n, h, h, c)).astype(np.float32)
+    flow = RNG.uniform(-5, 5, (n, h, h, 2)).astype(np.float32)
+    flow[0, 0, :8] = 0.0
+    flow[0, 1, :4, 0] = -2.0
+    flow[n - 1, 5, 5] = (400.0, -400.0)
+    ds, df, dt = dev(src), dev(flow), dev(tgt)
+    wgt = 0.75
+    warp = torch.full((n, h, h, 2), float('nan'), device='cuda')
+    gen = torch.full((n, h, h, c), float('nan'), device='cuda')
+    dflow = torch.full((n, h, h, 2), float('nan'), device='cuda')
+    loss = torch.zeros(4, device='cuda')
+    L().warp_resample_loss(n, h, h, h, h, c, ds.data_ptr(), df.data_ptr(), 2, dt.data_ptr(), c, kind, wgt, warp.data_ptr(),
+                           gen.data_ptr(), dflow.data_ptr(), 2, loss.data_ptr(), stream())
+    rwarp = ops.warp_pts_layer(flow)
+    rgen = ops.resampler_fwd(src, rwarp)
+    np.testing.assert_array_equal(host(warp), rwarp)
+    np.testing.assert_allclose(host(gen), rgen, rtol=0, atol=2e-6)
+    if kind == 2:
+        rl, rg = ops.euclidean_loss_fwd(rgen, tgt), ops.euclidean_loss_bwd(rgen, tgt, wgt)
+    else:
+        rl, rg = ops.l1_loss_fwd(rgen, tgt), ops.l1_loss_bwd(rgen, tgt, wgt)
+    np.testing.assert_allclose(host(loss)[0], wgt * rl, rtol=3e-6)
+    _, rdw = ops.resampler_bwd(src, rwarp, rg.astype(np.float32), need_ddata=False)
+    scale = np.abs(rdw).max()
+    np.testing.assert_allclose(host(dflow), rdw, rtol=0, atol=2e-5 * scale)
+    # the library's three separate launches give the same bits for gen and the flow gradient
+    gen2 = torch.empty_like(gen); g2 = torch.empty_like(gen); dflow2 = torch.empty_like(dflow); loss2 = torch.zeros(4, device='cuda')
+    L().warp_resample_fwd(n, h, h, h, h, c, ds.data_ptr(), df.data_ptr(), 2, None, gen2.data_ptr(), stream())
+    L().pixel_loss(n * h * h, c, gen2.data_ptr(), dt.data_ptr(), None, kind, wgt, loss2.data_ptr(), g2.data_ptr(), stream())
+    L().warp_resample_bwd(n, h, h, h, h, c, ds.data_ptr(), df.data_ptr(), 2, g2.data_ptr(), dflow2.data_ptr(), 2, stream())
+    np.testing.assert_array_equal(host(gen), host(gen2))
+    np.testing.assert_array_equal(host(dflow), host(dflow2))
+    np.testing.assert_allclose(host(loss)[0], host(loss2)[0], rtol=2e-6)
+    # no gradient requested: outputs and loss only
+    loss3 = torch.zeros(4, device='cuda')
+    L().warp_resample_loss(n, h, h, h, h, c, ds.data_ptr(), df.data_ptr(), 2, dt.data_ptr(), c, kind, wgt, None,
+                           gen2.data_ptr(), None, 0, loss3.data_ptr(), stream())
+    np.testing.assert_array_equal(host(gen), host(gen2))
+    assert host(loss3)[0] == host(loss)[0] or abs(host(loss3)[0] - host(loss)[0]) < 2e-6 * abs(host(loss)[0])
+
+
 def test_zero_flow_is_exact_transpose():
     """Known answer: zero flow returns the transposed source, bit-exact."""
     src = RNG.standard_normal((3, 128, 128, 3)).astype(np.float32)

@@ -46,6 +46,9 @@ LABEL = {
     'reduce_slabs_kernel<1>': 'reduce_slabs/scalar',
     'mv3d::igemm_splitk_epilogue': 'igemm_splitk_epilogue',
     'resample_kernel<false>': 'resample_fwd',
+    'resample_tile_kernel<2, 3>': 'resample_loss',
+    'resample_tile_kernel<0, 3>': 'resample_fwd',
+    'resample_tile_kernel<1, 3>': 'resample_bwd',
     'resample_kernel<true>': 'resample_bwd',
     'mv3d::pixel_loss_kernel': 'pixel_loss',
     'thin_deconv_s2_kernel<5, 2>': 'thin_deconv_s2<2>',
