@@ -267,6 +267,110 @@ __global__ __launch_bounds__(256) void thin_deconv_s2_kernel(const IgemmParams p
         }
 }
 
+// Tiled form for Ka = 32 (the flow / rgb / depth / mask heads): in the kernel above a lane walks its own 128-byte
+// channel row, so every load instruction touches 64 different cache lines and the 3 x 3 neighbourhoods are fetched
+// through L1 again and again (47 us for 42 MB).  Here a workgroup owns 16 x 16 positions of the input grid of one
+// image: the 18 x 18 x 32 halo is staged once with coalesced 16-byte loads (144-byte pixel pitch: ds_read_b128 of 16
+// consecutive pixels covers all banks), the filters sit next to it, and a thread computes its 2 x 2 x CC outputs from
+// LDS with packed FMAs (two partial sums per output, combined at the end).
+typedef float tdf2 __attribute__((ext_vector_type(2)));
+
+template <int KS, int CC, bool SW>
+__global__ __launch_bounds__(256) void thin_deconv_s2_tile_kernel(const IgemmParams p, int tiles_h, int tiles_w) {
+    constexpr int S = 2, KA = 32, PITCH = KA + 4;
+    constexpr int PT = (KS - S) / 2;
+    constexpr int DMIN = -((KS - 1 - PT) / S), DMAX = (S - 1 + PT) / S;
+    constexpr int HR = 16 + DMAX - DMIN, HPIX = HR * HR;
+    constexpr int NLOAD = (HPIX * (KA / 4) + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float* s_w = s_mem;                                      // [KS*KS][CC][KA]  (unused when SW)
+    float* s_a = s_mem + (SW ? 0 : KS * KS * CC * KA);       // [HPIX][PITCH]
+    const float* __restrict__ wt_g = p.Wt;
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w; b /= tiles_w;
+    const int th = b % tiles_h;
+    const int n = b / tiles_h;
+    const int u0 = th * 16, v0 = tw * 16;
+    // halo: every load is issued before the first LDS write (clamped addresses, zero outside the image)
+    {
+        float4 v[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int idx = tid + 256 * i;
+            const int pix = min(idx >> 3, HPIX - 1), c4 = idx & 7;
+            const int hr = pix / HR, hc = pix - hr * HR;
+            const int ih = u0 + DMIN + hr, iw = v0 + DMIN + hc;
+            const bool ok = (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+            const int ihc = min(max(ih, 0), p.Ha - 1), iwc = min(max(iw, 0), p.Wa - 1);
+            const float4 t = *reinterpret_cast<const float4*>(p.A + (int64_t)((n * p.Ha + ihc) * p.Wa + iwc) * p.a_ld + c4 * 4);
+            v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!SW)
+            for (int i = tid; i < KS * KS * CC * KA; i += 256) {
+                const int t = i / (CC * KA);
+                const int rem = i - t * CC * KA;
+                const int c = rem / KA, k = rem - c * KA;
+                s_w[i] = p.Wt[(int64_t)t * p.w_tap_stride + (int64_t)c * p.w_ns + (int64_t)k * p.w_ks];
+            }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < HPIX * 8) *reinterpret_cast<float4*>(s_a + (idx >> 3) * PITCH + (idx & 7) * 4) = v[i];
+        }
+    }
+    __syncthreads();
+    const int tu = tid >> 4, tv = tid & 15;
+    const int up = u0 + tu, vp = v0 + tv;
+    tdf2 acc[S * S][CC];
+#pragma unroll
+    for (int a = 0; a < S * S; ++a)
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[a][c] = (tdf2){0.f, 0.f};
+#pragma unroll
+    for (int dh = DMIN; dh <= DMAX; ++dh)
+#pragma unroll
+        for (int dw = DMIN; dw <= DMAX; ++dw) {
+            const float* src = s_a + ((tu + dh - DMIN) * HR + (tv + dw - DMIN)) * PITCH;
+            // two 4-channel groups per trip and a scheduling fence between trips: fully unrolled, hipcc hoists all 472
+            // LDS reads of the thread to the top and spills 5 KB of them to scratch
+#pragma unroll 2
+            for (int k = 0; k < KA; k += 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 v = *reinterpret_cast<const float4*>(src + k);
+                const tdf2 vlo = {v.x, v.y}, vhi = {v.z, v.w};
+#pragma unroll
+                for (int phh = 0; phh < S; ++phh)
+#pragma unroll
+                    for (int phw = 0; phw < S; ++phw) {
+                        const int P = phh + PT - S * dh, Q = phw + PT - S * dw;
+                        if (P < 0 || P >= KS || Q < 0 || Q >= KS) continue;      // folds at compile time
+                        const float* w = (SW ? wt_g + (int64_t)(P * KS + Q) * p.w_tap_stride : s_w + (P * KS + Q) * CC * KA) + k;
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) {
+                            // SW: the filter element is the same for every lane -> scalar loads, SGPR operands, no LDS traffic
+                            const float4 wv = *reinterpret_cast<const float4*>(w + (SW ? (int64_t)c * p.w_ns : c * KA));
+                            const tdf2 wlo = {wv.x, wv.y}, whi = {wv.z, wv.w};
+                            acc[phh * S + phw][c] = __builtin_elementwise_fma(vlo, wlo, acc[phh * S + phw][c]);
+                            acc[phh * S + phw][c] = __builtin_elementwise_fma(vhi, whi, acc[phh * S + phw][c]);
+                        }
+                    }
+            }
+        }
+    if (up >= p.Ha || vp >= p.Wa) return;
+#pragma unroll
+    for (int phh = 0; phh < S; ++phh)
+#pragma unroll
+        for (int phw = 0; phw < S; ++phw) {
+            const int64_t pix = (int64_t)(n * p.Hc + up * S + phh) * p.Wc + vp * S + phw;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const tdf2 a = acc[phh * S + phw][c];
+                p.Out[pix * p.c_ld + c] = epilogue_value(p, a[0] + a[1], pix, c);
+            }
+        }
+}
+
 // Convolution with a tiny image side (C <= 4: the RGB / depth / mask input layers e0, and the input
 // gradient of the flow / rgb heads): the filter row (kw*C <= 20 contiguous floats of an NHWC row) is
 // folded into the GEMM reduction.  One wave = 32 consecutive output pixels x 32 output channels;
@@ -980,6 +1084,27 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
         if (s2) {
             const int KS = ntaps_all == 25 ? 5 : 3;
             const size_t lds2 = (size_t)KS * KS * p.Cc * p.Ka * sizeof(float);
+            if (p.Ka == 32 && !(disabled_paths() & 131072)) {
+                const int HR = KS == 5 ? 18 : 17;
+                // filter rows contiguous along the reduction and 16-byte aligned: read them with scalar loads
+                // (measured 43 us against 37 us with the filters in LDS: scalar and LDS returns share one counter, so every
+                // use waits for all of them -- kept behind MV3D_DISABLE bit 262144 for experiments)
+                const bool sw = (disabled_paths() & 262144) && p.w_ks == 1 && p.w_ns % 4 == 0 && p.w_tap_stride % 4 == 0 &&
+                                (reinterpret_cast<uintptr_t>(p.Wt) & 15) == 0;
+                const size_t lds3 = (sw ? 0 : lds2) + (size_t)HR * HR * 36 * sizeof(float);
+                const int tiles_h = cdiv(p.Ha, 16), tiles_w = cdiv(p.Wa, 16);
+                const int blocks = p.N * tiles_h * tiles_w;
+                p.ksplit = 1;
+                static const char* tn3[4] = {"thin_deconv_s2<1>", "thin_deconv_s2<2>", "thin_deconv_s2<3>", "thin_deconv_s2<4>"};
+                return dispatch(stream, OpInfo{tn3[p.Cc - 1], flops, bytes}, [=](hipStream_t s) {
+#define MV3D_THINT(KS_, CC_) do { if (sw) thin_deconv_s2_tile_kernel<KS_, CC_, true><<<blocks, 256, lds3, s>>>(p, tiles_h, tiles_w); \
+                                  else thin_deconv_s2_tile_kernel<KS_, CC_, false><<<blocks, 256, lds3, s>>>(p, tiles_h, tiles_w); } while (0)
+                    if (KS == 5) { switch (p.Cc) { case 1: MV3D_THINT(5, 1); break; case 2: MV3D_THINT(5, 2); break; case 3: MV3D_THINT(5, 3); break; default: MV3D_THINT(5, 4); break; } }
+                    else { switch (p.Cc) { case 1: MV3D_THINT(3, 1); break; case 2: MV3D_THINT(3, 2); break; case 3: MV3D_THINT(3, 3); break; default: MV3D_THINT(3, 4); break; } }
+#undef MV3D_THINT
+                    return launched("thin_deconv_s2_tile_kernel");
+                });
+            }
             if (lds2 <= 64 * 1024) {
                 const int blocks = cdiv(p.N * p.Ha * p.Wa, 256);
                 p.ksplit = 1;
