@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Build profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs).
 
-    python tools/make_traffic.py gpurun_out/pmc_fetch2 gpurun_out/pmc_write2 > profiles/traffic.json
+    python tools/make_traffic.py profiles/r01_d_pmc_fetch_size.csv profiles/r01_d_pmc_write_size.csv > profiles/traffic.json
+    (arguments: the counter_collection.csv files of the two passes, or the rocprofv3 output directories holding them)
 
 Per MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KB; on gfx950 FETCH_SIZE under-reports by 2x
 (64-byte requests counted as 32) and is doubled here; WRITE_SIZE is used as is. Values are means over the launches of a
@@ -27,6 +28,14 @@ LABEL = {
     'fc_stream_b3_kernel<true, 2>': 'fc_stream_b3<dgrad>',
     'mv3d::fc_wgrad_b3_kernel': 'fc_wgrad_b3',
     'mv3d::bconv_split_all_kernel': 'bconv_split_all',
+    'thin_deconv_s2_tile_kernel<5, 2, false>': 'thin_deconv_s2<2>',
+    'smallc_b3_kernel<1, 5>': 'smallc_img2feat<N32>',
+    'wgrad_b3_kernel<5, 2, 4>': 'wgrad_b3<3x3,K64>',
+    'wgrad_b3_kernel<5, 2, 8>': 'wgrad_b3<3x3,K64>/stride2',
+    'bconvu_kernel<9, 3, 1, 1, 4>': 'bconv<small-img,128px,N32>/3x3',
+    'bconv_kernel<1, 1, 1, 4>': 'bconv<small-img,128px,N32>/deconv',
+    'bconvu_kernel<25, 5, 1, 1, 4>': 'bconv<1ph,128px,N32>',
+    'bconvu_kernel<25, 5, 1, 2, 2>': 'bconv<1ph,64px,N64>',
     # exact-fp32 kernels (round-1 'b' / 'c' profiles, MV3D_DISABLE=4096)
     'hconvp_kernel<25, 1, 1, false, 9, 8, 25, 25, 25>': 'hconvp<5x5,256px,N32,nmajorB>',
     'hconvp_kernel<25, 1, 1, false, 13, 4, 25, 25, 25>': 'hconvp<5x5,128px,N32,nmajorB>',
@@ -60,7 +69,7 @@ COUNTS = {}
 
 
 def means(d, counter):
-    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    f = d if d.endswith('.csv') else glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
