@@ -79,6 +79,7 @@ OTHER_FUNCS = {
     "mv3d_conv_workspace_bytes": (_sz, [_G]),
     "mv3d_fc_workspace_bytes": (_sz, [_i, _i, _i]),
     "mv3d_crc32c": (C.c_uint32, [_vp, _sz]),
+    "mv3d_set_diagnostics": (C.c_int, [_i]),
     "mv3d_filter_prepared_bytes": (_sz, [_G, _i]),
     "mv3d_filter_cache_table_bytes": (_sz, []),
     "mv3d_plan_create": (_vp, []),

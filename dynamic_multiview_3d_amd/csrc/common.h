@@ -34,12 +34,9 @@ inline int launched(const char* what) {
     return MV3D_OK;
 }
 
-// MV3D_DISABLE (diagnostics): bit 0 hconv, bit 1 wgrad_tile, bit 2 small_fc, bit 3 hconv 64-px tiles
-static inline int disabled_paths() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MV3D_DISABLE"); v = e ? atoi(e) : 0; }
-    return v;
-}
+// Diagnostics mask (dispatch rungs switched off): MV3D_DISABLE at load time, mv3d_set_diagnostics()
+// at run time.  One definition for all translation units (core.hip).
+int disabled_paths();
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

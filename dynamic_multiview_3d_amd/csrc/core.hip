@@ -1,5 +1,7 @@
 // Error reporting and recorded launch plans of libmv3d_hip.so.
 #include "common.h"
+#include <atomic>
+#include <cstdlib>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -23,6 +25,18 @@ struct mv3d_plan {
 };
 
 namespace mv3d {
+
+static std::atomic<int> g_disabled{-1};
+int disabled_paths() {
+    int v = g_disabled.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MV3D_DISABLE");
+        v = e ? atoi(e) : 0;
+        g_disabled.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 static thread_local char g_err[512] = "";
 static thread_local mv3d_plan* g_rec = nullptr;
 static thread_local int g_side = 0;
@@ -203,6 +217,14 @@ int mv3d_plan_profile_reset(mv3d_plan* p) {
     for (auto& o : p->ops) { o.total_ms = 0.0; o.runs = 0; }
     p->used = 0;
     return MV3D_OK;
+}
+
+// Replaces the diagnostics mask (initially MV3D_DISABLE); returns the previous one.  Affects dispatch decisions taken
+// afterwards: plans recorded earlier keep the kernels they were recorded with.
+int mv3d_set_diagnostics(int mask) {
+    const int old = mv3d::disabled_paths();
+    mv3d::g_disabled.store(mask < 0 ? 0 : mask, std::memory_order_relaxed);
+    return old;
 }
 
 // CRC-32C (Castagnoli), the checksum of the TFRecord framing (host only; slicing-by-8 tables built on first use).

@@ -65,6 +65,10 @@ typedef struct mv3d_epilogue {
 
 const char* mv3d_version(void);
 const char* mv3d_last_error(void);
+/* Diagnostics: replace the mask of disabled dispatch rungs (environment MV3D_DISABLE at load; bits in DESIGN.md 4.5);
+ * returns the previous mask.  Results never change beyond rounding; 4096 selects the exact fp32-MFMA kernels. */
+int mv3d_set_diagnostics(int mask);
+
 /* CRC-32C of a host buffer: the record checksum of the reference's TFRecord shards (multi_view_model/utils/read_tf_records.py:46-48
  * reads them through tf.TFRecordReader); used by dynamic_multiview_3d_amd/read_tf_records.py */
 uint32_t mv3d_crc32c(const void* data, size_t n);

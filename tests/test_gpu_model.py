@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from dynamic_multiview_3d_amd import _lib
 from oracle import models as omodels
 from tests.synth import appflow_feeds
 
@@ -295,3 +296,53 @@ def test_mv3d_models(variant):
     for _ in range(5):
         l1 = float(model.train_step())
     assert np.isfinite(l1) and l1 < l0
+
+
+@pytest.mark.gpu
+def test_fused_head_equals_the_three_launch_head(monkeypatch):
+    """Graph._fuse_resample_losses: the appearance-flow head as one launch (sampler + loss + sampler gradient) and as three
+    (MV3D_FUSE_RESAMPLE=0) give the same outputs, loss and parameter gradients; and the exact-fp32 rungs
+    (mv3d_set_diagnostics(4096)) stay within 1e-5 of the oracle on the whole model."""
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    from dynamic_multiview_3d_amd.graph import ResampleNode
+    feeds = appflow_feeds(np.random.default_rng(3), 2)
+    res = []
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('MV3D_FUSE_RESAMPLE', fuse)
+        model = AppearanceFlowModel({'batch_size': 2, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda')
+        g = model.graph
+        _perturb_biases(g)
+        node = [n for n in g.nodes if isinstance(n, ResampleNode)][0]
+        assert (node.fused_loss is not None) == (fuse == '1')
+        names = [o[0] for o in _lib.plan_ops(g.plan_fwd)]
+        assert ('resample_loss' in names) == (fuse == '1') and ('pixel_loss' in names) == (fuse == '0')
+        model.feed(**feeds)
+        g.run_forward()
+        g.run_backward()
+        torch.cuda.synchronize()
+        res.append((model.gen.numpy(), float(g.loss_buf[0]), g.get_gradients()))
+    (gen1, loss1, gr1), (gen0, loss0, gr0) = res
+    np.testing.assert_array_equal(gen1, gen0)
+    np.testing.assert_allclose(loss1, loss0, rtol=2e-6)
+    for k in gr0:
+        assert _rel(gr1[k], gr0[k]) < 1e-6, k
+
+    old = _lib.lib().set_diagnostics(4096)
+    try:
+        monkeypatch.setenv('MV3D_FUSE_RESAMPLE', '1')
+        model = AppearanceFlowModel({'batch_size': 2, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda')
+        g = model.graph
+        variables = _perturb_biases(g)
+        builder = omodels.appearance_flow_builder('base')
+        out, grads, tape = omodels.run(builder, {k: v.copy() for k, v in variables.items()}, feeds)
+        model.feed(**feeds)
+        g.run_forward()
+        g.run_backward()
+        torch.cuda.synchronize()
+        out, grads, tape = _oracle_at_device_kinks(model, builder, variables, feeds, out, grads, tape)
+        got = g.get_gradients()
+        worst = max(_rel(got[k], grads[k]) for k in grads)
+        assert worst < 2e-5, worst
+        assert _rel(model.gen.numpy(), out['gen']) < 1e-5
+    finally:
+        _lib.lib().set_diagnostics(old)

@@ -380,3 +380,46 @@ def test_errors_are_reported_not_launched():
         L().conv2d_fwd(C.byref(g), 1, 1, 1, None, None, 0, None)
     with pytest.raises(_lib.Mv3dError, match="null"):
         L().conv2d_fwd(C.byref(_lib.conv_geom(1, 8, 8, 4, 4, 3, 3, 1, 1)), None, 1, 1, None, None, 0, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Fallback rungs of the dispatch ladders: the same shapes through the kernels the default path
+# does not pick -- exact fp32 MFMA twins, generic implicit GEMM, generic (not unrolled) split-bf16 loop, slab filter
+# gradient, generic fc, one-thread-per-pixel resampler and thin deconv.  mv3d_set_diagnostics switches them in-process.
+RUNGS = {
+    'exact_fp32_mfma': 4096,
+    'generic_igemm_fp32': 4096 | 1 | 2 | 16 | 64,
+    'generic_bconv_loop': 8192,
+    'no_persistent_no_small_image': 128 | 1024,
+    'slab_filtgrad': 2 | 16384,
+    'generic_fc': 16 | 4,
+    'per_pixel_resampler_and_thin_deconv': 65536 | 131072 | 64,
+    'tiles_64px_off': 8,
+}
+
+
+@pytest.fixture
+def rung(request):
+    old = L().set_diagnostics(RUNGS[request.param])
+    yield request.param
+    L().set_diagnostics(old)
+
+
+@pytest.mark.parametrize("rung", list(RUNGS), indirect=True)
+def test_fallback_rungs_agree_with_the_oracle(rung):
+    for case in [(2, 64, 64, 32, 32, 5, 1), (2, 64, 64, 32, 32, 5, 2), (3, 16, 16, 64, 64, 5, 1), (4, 8, 8, 128, 128, 3, 1),
+                 (8, 4, 4, 256, 256, 3, 1), (2, 128, 128, 3, 32, 5, 2), (2, 32, 32, 32, 64, 5, 2)]:
+        test_conv2d_fwd_dgrad_wgrad(*case)
+    for case in [(2, 32, 32, 64, 32, 5, 2), (2, 64, 64, 32, 2, 5, 2), (4, 4, 4, 256, 128, 3, 2), (2, 64, 64, 32, 3, 5, 2)]:
+        test_deconv2d_fwd_dgrad_wgrad(*case)
+    for case in [(64, 4160, 512), (8, 200, 96), (5, 64, 19)]:
+        test_fc(*case)
+    test_resampler_fwd_bwd_random_and_edges()
+    test_zero_flow_is_exact_transpose()
+    test_conv_channel_slices_and_gmask()
+
+
+def test_set_diagnostics_returns_the_previous_mask():
+    old = L().set_diagnostics(4096)
+    assert L().set_diagnostics(old) == 4096
+    assert L().set_diagnostics(old) == old
