@@ -800,31 +800,54 @@ __global__ __launch_bounds__(256) void thin_filtgrad_kernel(const ThinFgParams p
     const int n_img = p.IR * p.IW * p.C;
     const int row_elems = p.IW * p.C;
     const int npx = p.TR * p.Wo;
+    const int inv_c = 65536 / p.C + 1;                    // e / C for e < 8192 (C <= 4)
+    const int inv_wo = (1 << 20) / p.Wo + 1;              // px / Wo for px < 4096
     for (int blk = b_begin; blk < b_end; ++blk) {
         const int n = blk / p.blocks_per_img, oh0 = (blk - n * p.blocks_per_img) * p.TR;
         const int ih0 = oh0 * p.sh - p.pt, iw0 = -p.pl;
         if (blk > b_begin) __syncthreads();
+        // Staging: every load of a batch is issued before the first LDS store of that batch, from clamped (always valid)
+        // addresses with the bounds test applied to the value.  A load under a branch inside a rolled loop leaves one
+        // request in flight per thread: the staging of a block then costs a dozen serial memory round trips.
         // image rows: one staged row per wave pass, lanes along the row (contiguous in global memory when img_ld == C)
         for (int r = wave; r < p.IR; r += 4) {
             const int ih = ih0 + r;
             const bool row_ok = (unsigned)ih < (unsigned)p.H;
             const float* src = p.img + (int64_t)((n * p.H + (row_ok ? ih : 0)) * p.W) * p.img_ld;
-            for (int e = lane; e < row_elems; e += 64) {
-                const int col = e / p.C, c = e - col * p.C;
-                const int iw = iw0 + col;
-                float v = 0.f;
-                if (row_ok && (unsigned)iw < (unsigned)p.W) v = src[(int64_t)iw * p.img_ld + c];
-                img_s[r * row_elems + e] = v;
+            for (int e0 = lane; e0 < row_elems; e0 += 64 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + 64 * u, row_elems - 1);
+                    const int col = (int)(((unsigned)e * (unsigned)inv_c) >> 16), c = e - col * p.C;
+                    const int iw = iw0 + col;
+                    const bool ok = row_ok && (unsigned)iw < (unsigned)p.W;
+                    const float t = src[(int64_t)(ok ? iw : 0) * p.img_ld + c];
+                    v[u] = ok ? t : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + 64 * u < row_elems) img_s[r * row_elems + e0 + 64 * u] = v[u];
             }
         }
         // feature rows: TR x Wo x 32 floats as float4
-        for (int i = tid; i < npx * 8; i += 256) {
-            const int c4 = i & 7, px = i >> 3;
-            const int r = px / p.Wo, ow = px - r * p.Wo;
-            const int oh = oh0 + r, kk = k0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oh < p.Ho && kk < p.K) v = *reinterpret_cast<const float4*>(p.feat + (int64_t)((n * p.Ho + oh) * p.Wo + ow) * p.feat_ld + kk);
-            *reinterpret_cast<float4*>(feat_s + (size_t)px * 32 + c4 * 4) = v;
+        for (int i0 = tid; i0 < npx * 8; i0 += 256 * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + 256 * u, npx * 8 - 1);
+                const int c4 = i & 7, px = i >> 3;
+                const int r = (int)(((unsigned)px * (unsigned)inv_wo) >> 20), ow = px - r * p.Wo;
+                const int oh = oh0 + r, kk = k0 + c4 * 4;
+                const bool ok = oh < p.Ho && kk < p.K;
+                const float4 t = *reinterpret_cast<const float4*>(p.feat + (int64_t)((n * p.Ho + (ok ? oh : 0)) * p.Wo + ow) * p.feat_ld + (ok ? kk : 0));
+                v[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < npx * 8) *reinterpret_cast<float4*>(feat_s + (size_t)(i >> 3) * 32 + (i & 7) * 4) = v[u];
+            }
         }
         __syncthreads();
         for (int r = 0; r < p.TR; ++r) {
