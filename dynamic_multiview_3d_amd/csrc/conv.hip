@@ -185,16 +185,66 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
 }
 
-// split-K tail: sum the partial slabs, apply the epilogue, store with the output's pixel stride
+// split-K tail: sum the partial slabs (in slab order: the result does not depend on the launch shape), apply the
+// epilogue, store with the output's pixel stride.  Eight slab rows are requested before the first add: with one load per
+// trip of a rolled loop the sum costs ksplit serial memory round trips.  VEC = 4: four consecutive channels per thread.
+template <int VEC>
 __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IgemmParams p) {
     const int64_t npix = (int64_t)p.N * p.Hc * p.Wc;
     const int64_t total = npix * p.Cc;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t nvec = total / VEC;
+    for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nvec; iv += (int64_t)gridDim.x * 256) {
+        const int64_t idx = iv * VEC;
         const int64_t pix = idx / p.Cc;
         const int col = (int)(idx - pix * p.Cc);
-        float s = 0.f;
-        for (int k = 0; k < p.ksplit; ++k) s += p.Part[(int64_t)k * total + idx];
-        p.Out[pix * p.c_ld + col] = epilogue_value(p, s, pix, col);
+        float s[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+        const float* src = p.Part + idx;
+        int k = 0;
+        for (; k + 8 <= p.ksplit; k += 8) {
+            float v[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if constexpr (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)(k + u) * total);
+                    v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+                } else {
+                    v[u][0] = src[(int64_t)(k + u) * total];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[e] += v[u][e];
+        }
+        for (; k < p.ksplit; ++k) {
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)k * total);
+                s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+            } else {
+                s[0] += src[(int64_t)k * total];
+            }
+        }
+        if constexpr (VEC == 4) {
+            float4 o;
+            o.x = epilogue_value(p, s[0], pix, col); o.y = epilogue_value(p, s[1], pix, col + 1);
+            o.z = epilogue_value(p, s[2], pix, col + 2); o.w = epilogue_value(p, s[3], pix, col + 3);
+            *reinterpret_cast<float4*>(p.Out + pix * p.c_ld + col) = o;
+        } else {
+            p.Out[pix * p.c_ld + col] = epilogue_value(p, s[0], pix, col);
+        }
+    }
+}
+
+static void launch_splitk_epilogue(const IgemmParams& e, int blocks, hipStream_t s) {
+    const int64_t total = (int64_t)e.N * e.Hc * e.Wc * e.Cc;
+    const bool vec = e.Cc % 4 == 0 && e.c_ld % 4 == 0 && ((reinterpret_cast<uintptr_t>(e.Out) | reinterpret_cast<uintptr_t>(e.Part)) & 15) == 0;
+    if (vec) {
+        const int b4 = (int)std::min<int64_t>(cdiv64(total / 4, 256), 4096);
+        igemm_splitk_epilogue<4><<<std::max(b4, 1), 256, 0, s>>>(e);
+    } else {
+        igemm_splitk_epilogue<1><<<blocks, 256, 0, s>>>(e);
     }
 }
 
@@ -1027,10 +1077,6 @@ static void fill_epilogue(IgemmParams& p, const mv3d_epilogue* e) {
     p.gact = e->gmask_act; p.gleak = e->gmask_leak; p.gref = (const float*)e->gmask_ref; p.g_ld = e->gmask_ld;
 }
 
-static void launch_splitk_epilogue(const IgemmParams& e, int blocks, hipStream_t s) {
-    igemm_splitk_epilogue<<<blocks, 256, 0, s>>>(e);
-}
-
 static int check_epilogue(const mv3d_epilogue* e, const char* who) {
     if (!e) return MV3D_OK;
     if (e->act < 0 || e->act > MV3D_ACT_TANH || e->gmask_act < 0 || e->gmask_act > MV3D_ACT_TANH)
@@ -1163,7 +1209,7 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
             const int64_t total = (int64_t)e.N * e.Hc * e.Wc * e.Cc;
             const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
             return dispatch(stream, OpInfo{"igemm_splitk_epilogue", 0.0, (double)total * 4.0 * (e.ksplit + 1)}, [=](hipStream_t s) {
-                igemm_splitk_epilogue<<<blocks, 256, 0, s>>>(e);
+                launch_splitk_epilogue(e, blocks, s);
                 return launched("igemm_splitk_epilogue");
             });
         }
@@ -1188,7 +1234,7 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
     const int64_t total = (int64_t)p.N * p.Hc * p.Wc * p.Cc;
     const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
     return dispatch(stream, OpInfo{"igemm_splitk_epilogue", 0.0, (double)total * 4.0 * (p.ksplit + 1)}, [=](hipStream_t s) {
-        igemm_splitk_epilogue<<<blocks, 256, 0, s>>>(p);
+        launch_splitk_epilogue(p, blocks, s);
         return launched("igemm_splitk_epilogue");
     });
 }

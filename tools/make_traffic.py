@@ -54,6 +54,8 @@ LABEL = {
     'reduce_slabs_kernel<4>': 'reduce_slabs',
     'reduce_slabs_kernel<1>': 'reduce_slabs/scalar',
     'mv3d::igemm_splitk_epilogue': 'igemm_splitk_epilogue',
+    'igemm_splitk_epilogue<4>': 'igemm_splitk_epilogue',
+    'igemm_splitk_epilogue<1>': 'igemm_splitk_epilogue/scalar',
     'resample_kernel<false>': 'resample_fwd',
     'resample_tile_kernel<2, 3>': 'resample_loss',
     'resample_tile_kernel<0, 3>': 'resample_fwd',
