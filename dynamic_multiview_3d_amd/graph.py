@@ -654,8 +654,9 @@ class Graph:
         # Extra (empty) segment boundary: the optimiser launches of the early (fc) buckets are held back until the main
         # stream is past the fc layers and the small-spatial convolutions -- kernels that stream HBM or wait on it like
         # Adam does and slow down 3-10x next to it -- and overlap the encoder's large MFMA-bound layers instead
-        # (measured best at ~0.65 of the backward launch list; 'fc' = right behind the last fully-connected layer).
-        mode = os.environ.get('MV3D_ADAM_GATE', '0.65')      # 'fc', 'none' or a fraction of the backward launch list
+        # (measured: 0.85-0.92 of the backward launch list beats 0.5-0.8 by ~1.5 %: the optimiser then runs next to the two
+        # largest data-gradient kernels and the tail of the filter-gradient chain; 'fc' = right behind the last fc layer).
+        mode = os.environ.get('MV3D_ADAM_GATE', '0.9')      # 'fc', 'none' or a fraction of the backward launch list
         if mode == 'none':
             gate = 0
         elif mode != 'fc':
