@@ -310,6 +310,16 @@ def main():
                                   "side-stream kernels)" if dom_name != 'adam' else
                                   "HIP events around the optimiser launch of the warm-up steps (N > 1: the timed region runs the product's "
                                   "bucketed Adam behind the all-reduces and carries no events)")})
+        # the same kernel with the GPU to itself (warm-up table pass, streams serialized): separates kernel quality from the
+        # cost of sharing HBM / CUs with the kernels it overlaps in the product schedule
+        tk = table.get(dom_name)
+        if tk and tk['ms'] > 0:
+            if tk['flops'] > 0:
+                a1, pk = tk['flops'] / (tk['ms'] * 1e-3) / 1e12, roof['peak']
+            else:
+                a1, pk = tk['bytes'] / (tk['ms'] * 1e-3) / 1e9, PEAK_HBM_GBS
+            roof["alone"] = {"avg_launch_ms": round(tk['ms'] / tk['launches'], 5), "achieved": round(a1, 1), "frac": round(a1 / pk, 4),
+                             "measured": "HIP events, warm-up steps, one stream"}
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
