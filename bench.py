@@ -203,15 +203,16 @@ def main():
     # events on that kernel's launches only.
     table = collections.OrderedDict()
     dominant = None
-    if args.warmup > 0:
+    if args.warmup > 0 or timing:
         one_step()
-    if timing and args.warmup > 1:
+    if timing:
+        n_table = max(args.warmup - 1, 2)       # the table (and with it `roofline`) exists for any --warmup; extra steps are untimed
         for plan in (g.plan_fwd, g.plan_bwd):
             lib.plan_profile_reset(plan)
             lib.plan_profile_select(plan, None)
             lib.plan_profile(plan, 1)
-        wev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.warmup - 1)]
-        for i in range(args.warmup - 1):
+        wev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_table)]
+        for i in range(n_table):
             serial_step(wev[i])
         torch.cuda.synchronize()
         collect(table)
