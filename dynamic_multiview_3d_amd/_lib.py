@@ -53,6 +53,9 @@ STATUS_FUNCS = {
     "mv3d_warp_resample_loss": [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp],
     "mv3d_pixel_loss": [_i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
     "mv3d_pixel_loss_strided": [_i64, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _f, _vp, _vp, _i, _vp],
+    "mv3d_tfrecord_open": [C.c_char_p, _i, C.POINTER(_vp)],
+    "mv3d_tfrecord_read": [_vp, _i, _i, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(_vp), C.POINTER(C.c_int)],
+    "mv3d_u8_to_unit_f32": [_i64, _vp, _vp, _vp],
     "mv3d_fill": [_vp, _i64, _f, _vp],
     "mv3d_adam_step": [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _f, _vp],
     "mv3d_filter_cache_bind": [_G, _i, _vp, _vp, _sz],
@@ -80,6 +83,7 @@ OTHER_FUNCS = {
     "mv3d_fc_workspace_bytes": (_sz, [_i, _i, _i]),
     "mv3d_crc32c": (C.c_uint32, [_vp, _sz]),
     "mv3d_set_diagnostics": (C.c_int, [_i]),
+    "mv3d_tfrecord_close": (None, [_vp]),
     "mv3d_filter_prepared_bytes": (_sz, [_G, _i]),
     "mv3d_filter_cache_table_bytes": (_sz, []),
     "mv3d_plan_create": (_vp, []),

@@ -17,6 +17,7 @@ UNITS = {
     "wgrad_tile.hip": [],
     "fc.hip": [],
     "elem.hip": ["-ffp-contract=off"],
+    "tfrecord.hip": ["-msse4.2"],       # host code only: the input thread's record reader (hardware crc32c)
 }
 COMMON = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -286,6 +286,16 @@ __global__ __launch_bounds__(256) void pixel_loss_dense_kernel(int64_t total4, i
     if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (weight / (float)pixels));
 }
 
+// raw uint8 image bytes -> float32 / 255 (read_tf_records.py:111: tf.cast(image, tf.float32) / 255.0), four pixels' worth per lane
+__global__ __launch_bounds__(256) void u8_to_unit_f32_kernel(int64_t count, const unsigned char* __restrict__ src, float* __restrict__ dst) {
+    const int64_t nvec = count >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const uchar4 b = reinterpret_cast<const uchar4*>(src)[i];
+        reinterpret_cast<float4*>(dst)[i] = make_float4((float)b.x / 255.0f, (float)b.y / 255.0f, (float)b.z / 255.0f, (float)b.w / 255.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) { const int64_t i = (nvec << 2) + threadIdx.x; dst[i] = (float)src[i] / 255.0f; }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* dst, int64_t count, float v) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) dst[i] = v;
 }
@@ -471,6 +481,15 @@ int mv3d_fill(void* dst, int64_t count, float value, void* stream) {
     return dispatch(stream, OpInfo{"fill", 0.0, 4.0 * count}, [=](hipStream_t s) {
         fill_kernel<<<grid_for(count), 256, 0, s>>>((float*)dst, count, value);
         return launched("fill_kernel");
+    });
+}
+
+int mv3d_u8_to_unit_f32(int64_t count, const void* src, void* dst, void* stream) {
+    if (count <= 0 || !src || !dst) return fail(MV3D_E_INVAL, "mv3d_u8_to_unit_f32: bad arguments");
+    if (((uintptr_t)src & 3) || ((uintptr_t)dst & 15)) return fail(MV3D_E_INVAL, "mv3d_u8_to_unit_f32: src must be 4-byte and dst 16-byte aligned");
+    return dispatch(stream, OpInfo{"u8_to_unit_f32", 0.0, 5.0 * count}, [=](hipStream_t s) {
+        u8_to_unit_f32_kernel<<<grid_for(count / 4 + 1), 256, 0, s>>>(count, (const unsigned char*)src, (float*)dst);
+        return launched("u8_to_unit_f32_kernel");
     });
 }
 

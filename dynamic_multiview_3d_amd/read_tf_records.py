@@ -15,8 +15,11 @@ Example{1: Features{1: map<string, Feature>}}, Feature{1: BytesList | 2: FloatLi
 
 Differences to the reference, by design: the reference shuffles file names per epoch and decodes with min(B, 10) threads
 into a 100*B-deep queue, so its batch order is non-deterministic; here the order is the (seeded) shuffled file order with
-records in file order, decoded by one background thread that keeps `prefetch` batches ahead and uploads them to the
-device on its own stream through pinned buffers.
+records in file order.  The input thread does not parse records in Python: csrc/tfrecord.hip (mv3d_tfrecord_read) checks the
+CRCs, walks the Example and copies the requested features into pinned batch buffers without the GIL; images travel as uint8
+and become float32 / 255 on the device (mv3d_u8_to_unit_f32) on the reader's stream, `prefetch` batches ahead of the step.
+The functions below (crc32c, parse_example, serialize_example, TFRecordWriter, read_records, decode_record) are the readable
+restatement of the same format, used by the writer and the tests.
 """
 import ctypes as C
 import glob
@@ -251,43 +254,79 @@ class TFRecordInput:
         self.thread = threading.Thread(target=self._produce, daemon=True)
         self.thread.start()
 
-    def _records(self):
+    def _files(self):
         while True:                                      # epochs: reshuffle the file order like string_input_producer
             files = list(self.files)
             if self.shuffle:
                 self.rng.shuffle(files)
             for f in files:
-                for rec in read_records(f, self.verify):
-                    yield rec
+                yield f
 
     def _produce(self):
+        """Input thread: the native reader (csrc/tfrecord.hip: framing, crc32c, Example parsing; no GIL held) copies the
+        records' features straight into pinned batch buffers -- images stay uint8 on the host and over PCIe -- which are
+        uploaded on the reader's stream and turned into float32 / 255 there (mv3d_u8_to_unit_f32)."""
+        reader = None
         try:
             import torch
+            lib = _lib.lib()
             cuda = torch.device(self.device).type == 'cuda'
             stream = torch.cuda.Stream(device=self.device) if cuda else None
-            recs = self._records()
-            while not self._stop:
-                host = {k: np.empty((self.batch,) + s, np.float32) for k, s in self.spec.items()}
-                for i in range(self.batch):
-                    d = decode_record(next(recs), self.spec)
-                    for k in host:
-                        host[k][i] = d[k]
-                out = {}
-                for k, a in host.items():
-                    t = torch.from_numpy(a)
-                    if cuda:
-                        t = t.pin_memory()
-                        with torch.cuda.stream(stream):
-                            t = t.to(self.device, non_blocking=True)
-                    out[k] = t
-                ev = None
+            names = list(self.spec)
+            kinds = [1 if len(self.spec[k]) == 1 else 0 for k in names]
+            sizes = [int(np.prod(self.spec[k])) * (4 if kd else 1) for k, kd in zip(names, kinds)]
+            c_names = (C.c_char_p * len(names))(*[RECORD_NAME.get(k, k).encode() for k in names])
+            c_kinds = (C.c_int * len(names))(*kinds)
+            c_sizes = (C.c_size_t * len(names))(*sizes)
+            nring = self.q.maxsize + 2                    # a staging set is reused only after its upload has completed
+            ring = []
+            for _ in range(nring):
+                bufs = [torch.empty((self.batch,) + self.spec[k], dtype=torch.float32 if kd else torch.uint8) for k, kd in zip(names, kinds)]
                 if cuda:
-                    ev = torch.cuda.Event()
-                    ev.record(stream)
+                    bufs = [b.pin_memory() for b in bufs]
+                ring.append((bufs, (C.c_void_p * len(names))(*[b.data_ptr() for b in bufs]), [None]))
+            files = self._files()
+            nread = C.c_int(0)
+            slot = 0
+            while not self._stop:
+                bufs, c_dst, done = ring[slot % nring]
+                slot += 1
+                if done[0] is not None:
+                    done[0].synchronize()
+                have = 0
+                while have < self.batch:
+                    if reader is None:
+                        reader = C.c_void_p()
+                        lib.tfrecord_open(next(files).encode(), 1 if self.verify else 0, C.byref(reader))
+                    lib.tfrecord_read(reader, self.batch - have, have, len(names), c_names, c_kinds, c_sizes, c_dst, C.byref(nread))
+                    have += nread.value
+                    if have < self.batch:                 # end of this file
+                        lib.tfrecord_close(reader)
+                        reader = None
+                out = {}
+                if cuda:
+                    with torch.cuda.stream(stream):
+                        for k, kd, b in zip(names, kinds, bufs):
+                            d = b.to(self.device, non_blocking=True)
+                            if not kd:
+                                f = torch.empty(d.shape, dtype=torch.float32, device=self.device)
+                                lib.u8_to_unit_f32(d.numel(), d.data_ptr(), f.data_ptr(), stream.cuda_stream)
+                                d = f
+                            out[k] = d
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                    done[0] = ev
+                else:
+                    ev = None
+                    for k, kd, b in zip(names, kinds, bufs):
+                        out[k] = b.clone() if kd else b.to(torch.float32) / np.float32(255.0)
                 self.q.put((out, ev))
         except BaseException as e:       # surfaced by next()
             self._err = e
             self.q.put((None, None))
+        finally:
+            if reader is not None:
+                _lib.lib().tfrecord_close(reader)
 
     def next(self):
         out, ev = self.q.get()

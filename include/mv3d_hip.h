@@ -69,6 +69,18 @@ const char* mv3d_last_error(void);
  * returns the previous mask.  Results never change beyond rounding; 4096 selects the exact fp32-MFMA kernels. */
 int mv3d_set_diagnostics(int mask);
 
+/* ---- input side (host): the reference's TFRecord shards, multi_view_model/utils/read_tf_records.py:46-85 -----------------
+ * mv3d_tfrecord_read copies feature k of up to max_records records into dst[k] + (first + i) * sizes[k] (host memory, e.g. a
+ * pinned batch buffer): kinds[k] = 0 a single bytes value of exactly sizes[k] bytes (raw uint8 image), 1 a float list of
+ * sizes[k] / 4 values.  *nread < max_records only at the end of the file.  CRC-32C of every record is checked when the
+ * reader was opened with verify_crc != 0.  mv3d_u8_to_unit_f32: device-side uint8 -> float32 / 255 (read_tf_records.py:111). */
+typedef struct mv3d_tfrecord_reader mv3d_tfrecord_reader;
+int mv3d_tfrecord_open(const char* path, int verify_crc, mv3d_tfrecord_reader** out);
+int mv3d_tfrecord_read(mv3d_tfrecord_reader* r, int max_records, int first, int nfeat, const char* const* names, const int* kinds,
+                       const size_t* sizes, void* const* dst, int* nread);
+void mv3d_tfrecord_close(mv3d_tfrecord_reader* r);
+int mv3d_u8_to_unit_f32(int64_t count, const void* src, void* dst, void* stream);
+
 /* CRC-32C of a host buffer: the record checksum of the reference's TFRecord shards (multi_view_model/utils/read_tf_records.py:46-48
  * reads them through tf.TFRecordReader); used by dynamic_multiview_3d_amd/read_tf_records.py */
 uint32_t mv3d_crc32c(const void* data, size_t n);

@@ -107,3 +107,85 @@ def test_missing_feature_and_wrong_size(tmp_path):
     with pytest.raises(KeyError):
         R.decode_record(rec, {'image1': (128, 128, 3)})
     assert R.decode_record(rec, {'disp': (2,)})['disp'].tolist() == [1.0, 2.0]
+
+
+# --------------------------------------------------------------------------------------------------- native reader
+def _write_shards(tmp_path, nfiles=2, per_file=5, seed=0):
+    rng = np.random.default_rng(seed)
+    recs = []
+    for f in range(nfiles):
+        with R.TFRecordWriter(str(tmp_path / ('%d.tfrecords' % f))) as w:
+            for _ in range(per_file):
+                a = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)
+                b = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)
+                d = rng.uniform(-1, 1, 2).astype(np.float32)
+                recs.append((a, b, d))
+                w.write(R.serialize_example({'image0': a.tobytes(), 'image1': b.tobytes(), 'depth0': a[..., :1].tobytes(),
+                                             'depth1': b[..., :1].tobytes(), 'displacement': d}))
+    return recs
+
+
+def test_native_reader_feeds_batches_across_files_and_epochs(tmp_path):
+    """csrc/tfrecord.hip behind TFRecordInput: same values as the Python restatement (decode_record), records in file
+    order, batches that straddle file boundaries, a second epoch after the last file (test_mode: no shuffle)."""
+    recs = _write_shards(tmp_path)
+    conf = {'batch_size': 4, 'data_dir': str(tmp_path), 'train_val_split': 1.0, 'test_mode': ''}
+    shapes = {'image0': (4, 128, 128, 3), 'image1': (4, 128, 128, 3), 'depth_image0': (4, 128, 128, 1), 'disp': (4, 2)}
+    inp = R.TFRecordInput(conf, shapes, training=True, device='cpu')
+    try:
+        seen = 0
+        for _ in range(4):                                   # 16 records out of 10: wraps into the second epoch
+            out = inp.next()
+            for i in range(4):
+                a, b, d = recs[(seen + i) % 10]
+                ref = R.decode_record(R.serialize_example({'image0': a.tobytes(), 'image1': b.tobytes(), 'depth0': a[..., :1].tobytes(),
+                                                           'depth1': b[..., :1].tobytes(), 'displacement': d}),
+                                      {'image0': (128, 128, 3), 'depth_image0': (128, 128, 1), 'disp': (2,)})
+                np.testing.assert_array_equal(out['image0'][i].numpy(), ref['image0'])
+                np.testing.assert_array_equal(out['depth_image0'][i].numpy(), ref['depth_image0'])
+                np.testing.assert_array_equal(out['disp'][i].numpy(), ref['disp'])
+                np.testing.assert_array_equal(out['image1'][i].numpy(), b.astype(np.float32) / np.float32(255))
+            seen += 4
+    finally:
+        inp.close()
+
+
+def test_native_reader_reports_bad_records(tmp_path):
+    import ctypes as C
+    from dynamic_multiview_3d_amd import _lib
+    lib = _lib.lib()
+    _write_shards(tmp_path, nfiles=1, per_file=2)
+    path = str(tmp_path / '0.tfrecords')
+
+    def read(names, kinds, sizes, verify=1, n=2):
+        r = C.c_void_p()
+        lib.tfrecord_open(path.encode(), verify, C.byref(r))
+        bufs = [np.zeros(n * s, np.uint8) for s in sizes]
+        nread = C.c_int(0)
+        try:
+            lib.tfrecord_read(r, n, 0, len(names), (C.c_char_p * len(names))(*[x.encode() for x in names]), (C.c_int * len(names))(*kinds),
+                              (C.c_size_t * len(names))(*sizes), (C.c_void_p * len(names))(*[b.ctypes.data for b in bufs]), C.byref(nread))
+        finally:
+            lib.tfrecord_close(r)
+        return nread.value, bufs
+
+    n, bufs = read(['displacement', 'image1'], [1, 0], [8, 49152], n=5)
+    assert n == 2 and bufs[0].view(np.float32).shape == (10,)                  # end of file after two records
+    with pytest.raises(_lib.Mv3dError, match="no feature 'image7'"):
+        read(['image7'], [0], [49152])
+    with pytest.raises(_lib.Mv3dError, match="has 49152 bytes, expected 100"):
+        read(['image0'], [0], [100])
+    with pytest.raises(_lib.Mv3dError, match="expected 12"):
+        read(['displacement'], [1], [12])
+    raw = bytearray(open(path, 'rb').read())
+    raw[5000] ^= 1
+    open(path, 'wb').write(raw)
+    with pytest.raises(_lib.Mv3dError, match='crc32c mismatch'):
+        read(['image0'], [0], [49152])
+    n, _ = read(['image0'], [0], [49152], verify=0)                            # unchecked: the flipped bit goes through
+    assert n == 2
+    open(path, 'wb').write(raw[:60000])
+    with pytest.raises(_lib.Mv3dError, match='truncated record'):
+        read(['image0'], [0], [49152], verify=0)
+    with pytest.raises(_lib.Mv3dError, match='cannot open'):
+        lib.tfrecord_open(str(tmp_path / 'nope').encode(), 1, C.byref(C.c_void_p()))
