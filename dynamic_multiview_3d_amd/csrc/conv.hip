@@ -847,7 +847,6 @@ __global__ __launch_bounds__(256) void thin_filtgrad_kernel(const ThinFgParams p
         for (int e = 0; e < 4; ++e) acc[j][e] = tf2{0.f, 0.f};
     tf2 bsum[4] = {tf2{0.f, 0.f}, tf2{0.f, 0.f}, tf2{0.f, 0.f}, tf2{0.f, 0.f}};
     const int b_begin = slab * p.blocks_per_slab, b_end = min(b_begin + p.blocks_per_slab, p.blocks_total);
-    const int n_img = p.IR * p.IW * p.C;
     const int row_elems = p.IW * p.C;
     const int npx = p.TR * p.Wo;
     const int inv_c = 65536 / p.C + 1;                    // e / C for e < 8192 (C <= 4)
