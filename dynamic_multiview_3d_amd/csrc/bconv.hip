@@ -616,12 +616,14 @@ __global__ __launch_bounds__(512) void bconvw_kernel(const IgemmParams p, const 
 // LDS row stride: 16 consecutive lanes of a ds_read_b128 group must land on 16 distinct 4-bank slots.
 // With 144-byte pixels that holds inside a tile row; across tile rows it needs the row stride
 // = 0 (mod 256 B) for 16-pixel rows and = 128 (mod 256 B) for 8-pixel rows (MI355X_MICROARCH.md, LDS lane groups).
-void bconv_set_rows(HconvExtra* x) {
+void bconv_set_rows(HconvExtra* x, int stride_h) {
     // exact for dividends < 2^20 / divisor (halo pixel indices stay below a few thousand)
     x->inv_hc = ((1 << 20) + x->HC - 1) / x->HC;
     x->inv_hri = x->HRi > 0 ? ((1 << 20) + x->HRi - 1) / x->HRi : 0;
     int rb = x->HC * BC_PIXB;
+    static const int s2rows = getenv("MV3D_BC_S2ROWS") ? atoi(getenv("MV3D_BC_S2ROWS")) : 1;
     if (x->TW == 16) rb = (rb + 255) & ~255;
+    else if (x->TW == 8 && stride_h == 2 && s2rows) rb = ((rb + 63) & ~127) + 64;     // two halo rows per tile row: 2 * rb = 128 mod 256
     else if (x->TW == 8) rb = ((rb + 127) & ~255) + 128;
     x->row_bytes = rb;
 }

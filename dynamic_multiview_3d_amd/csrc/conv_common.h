@@ -70,7 +70,7 @@ size_t bconv_filter_bytes(const IgemmParams& p, int NT);
 int bconv_lds_bytes(const HconvExtra& x);
 size_t bconv_prepared_bytes(const IgemmParams& p);        // 0: this problem never uses a prepared filter
 int bconv_cache_bind(const IgemmParams& p, void* prepared, size_t bytes);
-void bconv_set_rows(HconvExtra* x);
+void bconv_set_rows(HconvExtra* x, int stride_h = 1);
 int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid,
                  void* wfrag, void* stream, const char* name, const char* who, double flops, double bytes);
 

@@ -476,7 +476,7 @@ static bool pick_tile(const IgemmParams& p, int PIX, int Hp, int Wp, int dh_span
         const int th = cdiv(Hp, TH), tw = cdiv(Wp, TW);
         const int HR = (TH - 1) * p.sa_h + dh_span, HC = (TW - 1) * p.sa_w + dw_span;
         size_t lds = (size_t)HR * HC * 33 * sizeof(float);
-        if (b3) { HconvExtra t = {}; t.HC = HC; t.HR = HR; t.TW = TW; bconv_set_rows(&t); lds = (size_t)bconv_lds_bytes(t); }
+        if (b3) { HconvExtra t = {}; t.HC = HC; t.HR = HR; t.TW = TW; bconv_set_rows(&t, p.sa_h); lds = (size_t)bconv_lds_bytes(t); }
         if (lds > lds_cap) continue;
         const int64_t cost = (int64_t)th * tw * (PIX * 64 + HR * HC);
         if (best_cost < 0 || cost < best_cost) {
@@ -531,7 +531,7 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
             const size_t lds = (size_t)x.HR * x.HC * 33 * sizeof(float);
             const int tiles = cdiv(p.N, x.G), ny = cdiv(p.Cc, 32);
             const int zph = (nph == 4) ? 4 : 1;
-            bconv_set_rows(&x);
+            bconv_set_rows(&x, p.sa_h);
             const size_t wfb = bconv_filter_bytes(p, 1);
             if (b3 && bconv_lds_bytes(x) <= 150 * 1024 && ws && ws_bytes >= wfb && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
                 IgemmParams q = p;
@@ -635,7 +635,7 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
                 bx.chunks = cdiv(p.Ka, 32);
                 bx.ntaps_total = ntaps;
                 { const char* e = getenv("MV3D_DBG"); bx.dbg = e ? atoi(e) : 0; }
-                bconv_set_rows(&bx);
+                bconv_set_rows(&bx, p.sa_h);
                 IgemmParams q = p;
                 q.ksplit = 1;
                 dim3 grid(p.N * bx.tiles_h * bx.tiles_w, cdiv(p.Cc, 32 * NT), bx.phase_split ? 4 : 1);
