@@ -687,6 +687,7 @@ static int launch_bconv_t(const IgemmParams& p, const HconvExtra& x, dim3 grid, 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    if (x.ksplit > 1) name = intern_label("%s+ksplit", name);
     return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
         bconv_kernel<NPH, MT, NT, WAVES><<<grid, WAVES * 64, lds, s>>>(p, x, wf, ntiles);
         return launched(who);
@@ -704,6 +705,9 @@ static int launch_bconvu_t(const IgemmParams& p, const HconvExtra& x, dim3 grid,
     }
     HconvExtra xp = x;
     xp.n_tiles = (int)grid.x;
+    // the planner's label names the tile plan ("bconv<1ph,256px,N32>"); this instance is the unrolled kernel for NTAPS taps
+    name = intern_label("bconvu<%s,%s%dpx,N%d%s>", NTAPS == 25 ? "5x5" : "3x3", x.G > 1 ? "small-img," : "", 32 * MT * WAVES, 32 * NT,
+                        x.ksplit > 1 ? ",ksplit" : "");
     static int wg_per_cu = -1;
     if (wg_per_cu < 0) { const char* e = getenv("MV3D_BC_PERSIST"); wg_per_cu = e ? atoi(e) : 2; }
     dim3 pg = grid;
@@ -729,6 +733,7 @@ static int launch_bconvw_t(const IgemmParams& p, const HconvExtra& x, dim3 grid,
     }
     HconvExtra xp = x;
     xp.n_tiles = (int)grid.x;
+    name = intern_label("bconvw<%s,256px,N32>", NTAPS == 25 ? "5x5" : "3x3");
     const size_t lds = 2 * (size_t)bconv_lds_bytes(x) + 256 * 32 * sizeof(float);
     dim3 pg(std::min<int>((int)grid.x, std::max(1, 256 / (int)grid.y)), grid.y, 1);
     return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {

@@ -17,6 +17,11 @@ struct OpInfo {
     double bytes;
 };
 
+// Kernel labels live for the life of the process (OpInfo keeps the pointer): intern_label returns one stable copy per
+// distinct text.  A label names ONE kernel instance (template arguments included), so that the label-coverage test
+// (tests/test_label_coverage.py) can tie the launches of a recorded step to the kernels the parity tests ran.
+const char* intern_label(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
 bool recording();
 void record(std::function<int(hipStream_t)> fn, const OpInfo& info);
 

@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <mutex>
+#include <set>
+#include <string>
 
 struct PlanOp {
     std::function<int(hipStream_t)> fn;
@@ -47,6 +50,17 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+const char* intern_label(const char* fmt, ...) {
+    char buf[128];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    static std::mutex mu;
+    static std::set<std::string>* labels = new std::set<std::string>();      // never destroyed: plans may outlive static teardown
+    std::lock_guard<std::mutex> lk(mu);
+    return labels->insert(buf).first->c_str();
 }
 bool recording() { return g_rec != nullptr; }
 void record(std::function<int(hipStream_t)> fn, const OpInfo& info) { g_rec->ops.push_back(PlanOp{std::move(fn), info, 0.0, 0, true, g_side}); }

@@ -1,6 +1,11 @@
-"""A second, independent evaluator with oracle.graph.Tape's interface: torch CPU ops +
-autograd in float64.  Running oracle.models builders on it checks the oracle's hand-written
-reverse pass (closures in oracle/graph.py) against autograd over whole model graphs."""
+"""A second, independent CPU evaluator with oracle.graph.Tape's interface: torch CPU ops + autograd -- TEST INFRASTRUCTURE ONLY.
+
+Two uses: (1) float64: running the oracle.models builders on it checks the numpy oracle's hand-written reverse pass
+(closures in oracle/graph.py) against autograd over whole model graphs (tests/test_oracle_models.py, tests/golden/make_golden.py);
+(2) float32: bench.py's `cpu_baseline` times it on the host cores -- the same restated TF-1.3 graph (SAME padding,
+conv2d_transpose as input-gradient, tf.contrib.resampler, abs-based lrelu, TF-Adam) on a multi-threaded CPU convolution
+library (oneDNN behind torch), which is what "the reference graph on the node's host cores" looks like when TensorFlow 1.3
+itself cannot run offline.  PARITY UNPINNED like the rest of oracle/."""
 from collections import OrderedDict
 import numpy as np
 import torch
@@ -35,9 +40,10 @@ def _deconv_same(x, w, out_hw, s):
 
 
 class TorchTape:
-    def __init__(self, variables):
-        self.params = OrderedDict((k, torch.tensor(np.asarray(v, np.float64), requires_grad=True))
-                                  for k, v in variables.items())
+    def __init__(self, variables, dtype=np.float64, params=None):
+        self.dtype = dtype
+        self.params = params if params is not None else OrderedDict(
+            (k, torch.tensor(np.asarray(v, dtype), requires_grad=True)) for k, v in variables.items())
         self._scope = []
 
     def variable_scope(self, name):
@@ -55,7 +61,7 @@ class TorchTape:
         return self.params['/'.join(self._scope + [name])]
 
     def const(self, v):
-        return TNode(torch.tensor(np.asarray(v, np.float64)), False)
+        return TNode(torch.tensor(np.asarray(v, self.dtype)), False)
 
     def conv2d_msra(self, x, output_dim, k_h, k_w, d_h, d_w, name):
         with self.variable_scope(name):
@@ -80,7 +86,7 @@ class TorchTape:
 
     def warp_pts_layer(self, flow, name='warp_pts'):
         n, h, w, _ = flow.t.shape
-        return TNode(flow.t + torch.tensor(ops.coords(h, w, n, np.float64)))
+        return TNode(flow.t + torch.tensor(ops.coords(h, w, n, self.dtype)))
 
     def resample_layer(self, src, warp, name='tgt_img'):
         n, h, w, c = src.t.shape
@@ -131,3 +137,38 @@ def run_torch(builder, variables, feeds):
     outs = OrderedDict((k, n.t.detach().numpy()) for k, n in out.items())
     grads = OrderedDict((k, p.grad.numpy()) for k, p in t.params.items() if p.grad is not None)
     return outs, grads
+
+
+class TorchTrainer:
+    """fp32 train step of a builder's graph on torch CPU ops: forward, autograd reverse pass, TF ApplyAdam
+    (epsilon outside the bias correction) over every variable with a gradient.  Used by bench.py's
+    cpu_baseline only."""
+
+    def __init__(self, builder, variables, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.builder = builder
+        self.tape = TorchTape(variables, dtype=np.float32)
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        self.m = {k: torch.zeros_like(p) for k, p in self.tape.params.items()}
+        self.v = {k: torch.zeros_like(p) for k, p in self.tape.params.items()}
+        self.b1p, self.b2p = beta1, beta2
+
+    def step(self, feeds):
+        t = self.tape
+        for p in t.params.values():
+            p.grad = None
+        out = self.builder(t, {k: t.const(v) for k, v in feeds.items()})
+        loss = out['loss'].t
+        loss.backward()
+        alpha = self.lr * (1.0 - self.b2p) ** 0.5 / (1.0 - self.b1p)
+        with torch.no_grad():
+            for k, p in t.params.items():
+                g = p.grad
+                if g is None:
+                    continue
+                m, v = self.m[k], self.v[k]
+                m.add_(g - m, alpha=1.0 - self.beta1)
+                v.add_(g * g - v, alpha=1.0 - self.beta2)
+                p.sub_(alpha * m / (v.sqrt() + self.eps))
+        self.b1p *= self.beta1
+        self.b2p *= self.beta2
+        return float(loss)

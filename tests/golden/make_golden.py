@@ -4,7 +4,7 @@
 The reference (Python 2 + TensorFlow 1.3) cannot run in this environment and ships no golden vectors of its own
 (SURVEY.md section 8c), so these vectors are produced by the oracle (oracle/ops.py, the CPU restatement of the TF-1.3
 semantics) and, before being written, cross-checked against an independent float64 torch implementation
-(tests/torch_tape.py helpers / torch.nn.functional + autograd); the script aborts if the two disagree by more than 2e-6
+(oracle/torch_tape.py helpers / torch.nn.functional + autograd); the script aborts if the two disagree by more than 2e-6
 of the tensor maximum.  They pin the oracle against regressions and give the HIP library fixed vectors to hit; they do not
 replace a run of the reference ("parity unpinned").
 

@@ -1,0 +1,194 @@
+"""Per-layer parity AT THE BENCHMARKED SHAPES: every conv / deconv / fc layer of the timed configurations, at the batch
+they are timed at, through the C ABI against oracle/ops.py -- forward (bias + activation epilogue), data gradient (with the
+fused act'(saved output) mask the model's reverse pass uses) and filter / bias gradient, on the pixel strides of the concat
+buffers the model really reads and writes.  tests/test_label_coverage.py proves (on the CPU) that these cases dispatch every
+kernel instance the recorded steps launch.
+
+Tolerance: 2e-5 of the tensor maximum per op (split-bf16 products drop terms below 2^-16 relative; fp32 accumulation order
+differs from BLAS); north_star's bar is 1e-3."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+from oracle import models as omodels
+from dynamic_multiview_3d_amd import _lib
+from tests import layer_cases as LC
+from tests.gpu_utils import dev, host, stream, Ws, rel_err, conv_ws
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def L():
+    return _lib.lib()
+
+
+def _wide(rng, shape, ld):
+    """dense random tensor `shape` embedded at channel 0 of a buffer with pixel stride ld"""
+    buf = rng.standard_normal(shape[:-1] + (ld,)).astype(np.float32)
+    return buf, np.ascontiguousarray(buf[..., :shape[-1]])
+
+
+def _slopes(saved):
+    return np.where(saved > 0, 1.0, np.where(saved < 0, 0.2, 0.6)).astype(np.float32)
+
+
+def run_conv_case(case, seed=0):
+    kind, n, h, w, c, k, ksz, s, img_ld, feat_ld, need_dx = case
+    rng = np.random.default_rng(seed)
+    g = _lib.conv_geom(n, h, w, c, k, ksz, ksz, s, s, img_ld, feat_ld)
+    ho, wo = g.Ho, g.Wo
+    ws = conv_ws(g)
+    if kind == LC.CONV:
+        xbuf, x = _wide(rng, (n, h, w, c), img_ld)
+        wt = (rng.standard_normal((ksz, ksz, c, k)) / np.sqrt(ksz * ksz * c)).astype(np.float32)
+        b = rng.standard_normal(k).astype(np.float32)
+        dxb, dw_, db_ = dev(xbuf), dev(wt), dev(b)
+        ybuf = torch.full((n, ho, wo, feat_ld), 7.0, device='cuda')
+        epi = _lib.epilogue(db_.data_ptr(), _lib.ACT_LRELU, 0.2)
+        L().conv2d_fwd(C.byref(g), dxb.data_ptr(), dw_.data_ptr(), ybuf.data_ptr(), C.byref(epi), ws.ptr, ws.bytes, stream())
+        ref = ops.absact_fwd(ops.conv2d_fwd(x, wt, b, s, s), 'lrelu')
+        got = host(ybuf)
+        assert rel_err(got[..., :k], ref) < TOL
+        assert np.all(got[..., k:] == 7.0)                                  # channels outside the slice are untouched
+        dybuf, dy = _wide(rng, ref.shape, feat_ld)
+        rdx, rdw, rdb = ops.conv2d_bwd(x, wt, dy, s, s, need_dx=need_dx)
+        ddy = dev(dybuf)
+        if need_dx:
+            saved = rng.standard_normal(xbuf.shape).astype(np.float32)
+            saved[:, ::3, ::2, :] = 0.0                                       # exact zeros: slope 0.6 (sign(0) = 0)
+            dsaved = dev(saved)
+            gxb = torch.full((n, h, w, img_ld), 7.0, device='cuda')
+            epi = _lib.epilogue(None, 0, 0.2, _lib.ACT_LRELU, 0.2, dsaved.data_ptr(), img_ld)
+            L().conv2d_dgrad(C.byref(g), ddy.data_ptr(), dw_.data_ptr(), gxb.data_ptr(), C.byref(epi), ws.ptr, ws.bytes, stream())
+            got = host(gxb)
+            assert rel_err(got[..., :c], rdx * _slopes(saved[..., :c])) < TOL
+            assert np.all(got[..., c:] == 7.0)
+        gw = torch.full(wt.shape, float('nan'), device='cuda')
+        gb = torch.full((k,), float('nan'), device='cuda')
+        L().conv2d_wgrad(C.byref(g), dxb.data_ptr(), ddy.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.ptr, ws.bytes, stream())
+        assert rel_err(host(gw), rdw) < TOL
+        assert rel_err(host(gb), rdb) < TOL
+    else:
+        xbuf, x = _wide(rng, (n, ho, wo, k), feat_ld)                        # feature side in
+        wt = (rng.standard_normal((ksz, ksz, c, k)) / np.sqrt(ksz * ksz * k)).astype(np.float32)
+        dxb, dw_ = dev(xbuf), dev(wt)
+        ybuf = torch.full((n, h, w, img_ld), 7.0, device='cuda')
+        act = _lib.ACT_LRELU if c > 4 else _lib.ACT_NONE
+        epi = _lib.epilogue(None, act, 0.2)
+        L().deconv2d_fwd(C.byref(g), dxb.data_ptr(), dw_.data_ptr(), ybuf.data_ptr(), C.byref(epi), ws.ptr, ws.bytes, stream())
+        ref = ops.deconv2d_fwd(x, wt, (h, w), s, s)
+        if c > 4:
+            ref = ops.absact_fwd(ref, 'lrelu')
+        got = host(ybuf)
+        assert rel_err(got[..., :c], ref) < TOL
+        assert np.all(got[..., c:] == 7.0)
+        dybuf, dy = _wide(rng, ref.shape, img_ld)
+        rdx, rdw = ops.deconv2d_bwd(x, wt, dy, s, s)
+        ddy = dev(dybuf)
+        saved = rng.standard_normal(xbuf.shape).astype(np.float32)
+        saved[:, ::3, ::2, :] = 0.0
+        dsaved = dev(saved)
+        gxb = torch.full((n, ho, wo, feat_ld), 7.0, device='cuda')
+        epi = _lib.epilogue(None, 0, 0.2, _lib.ACT_LRELU, 0.2, dsaved.data_ptr(), feat_ld)
+        L().deconv2d_dgrad(C.byref(g), ddy.data_ptr(), dw_.data_ptr(), gxb.data_ptr(), C.byref(epi), ws.ptr, ws.bytes, stream())
+        got = host(gxb)
+        assert rel_err(got[..., :k], rdx * _slopes(saved[..., :k])) < TOL
+        assert np.all(got[..., k:] == 7.0)
+        gw = torch.full(wt.shape, float('nan'), device='cuda')
+        L().deconv2d_wgrad(C.byref(g), dxb.data_ptr(), ddy.data_ptr(), gw.data_ptr(), ws.ptr, ws.bytes, stream())
+        assert rel_err(host(gw), rdw) < TOL
+
+
+def run_fc_case(case, seed=0):
+    B, fin, fout, x_ld, y_ld = case
+    rng = np.random.default_rng(seed)
+    xbuf, x = _wide(rng, (B, fin), x_ld)
+    m = (rng.standard_normal((fin, fout)) / np.sqrt(fin)).astype(np.float32)
+    b = rng.standard_normal(fout).astype(np.float32)
+    ws = Ws(int(L().fc_workspace_bytes(B, fin, fout)))
+    dxb, dm, db = dev(xbuf), dev(m), dev(b)
+    ybuf = torch.full((B, y_ld), 7.0, device='cuda')
+    epi = _lib.epilogue(db.data_ptr(), _lib.ACT_LRELU, 0.2)
+    L().fc_fwd(B, fin, fout, dxb.data_ptr(), x_ld, dm.data_ptr(), ybuf.data_ptr(), y_ld, C.byref(epi), ws.ptr, ws.bytes, stream())
+    ref = ops.absact_fwd(ops.linear_fwd(x, m, b), 'lrelu')
+    got = host(ybuf)
+    assert rel_err(got[:, :fout], ref) < TOL
+    assert np.all(got[:, fout:] == 7.0)
+    dybuf, dy = _wide(rng, ref.shape, y_ld)
+    rdx, rdm, rdb = ops.linear_bwd(x, m, dy)
+    ddy = dev(dybuf)
+    saved = rng.standard_normal(xbuf.shape).astype(np.float32)
+    saved[::3, ::2] = 0.0
+    dsaved = dev(saved)
+    gxb = torch.full((B, x_ld), 7.0, device='cuda')
+    epi = _lib.epilogue(None, 0, 0.2, _lib.ACT_LRELU, 0.2, dsaved.data_ptr(), x_ld)
+    L().fc_dgrad(B, fin, fout, ddy.data_ptr(), y_ld, dm.data_ptr(), gxb.data_ptr(), x_ld, C.byref(epi), ws.ptr, ws.bytes, stream())
+    got = host(gxb)
+    assert rel_err(got[:, :fin], rdx * _slopes(saved[:, :fin])) < TOL
+    assert np.all(got[:, fin:] == 7.0)
+    gm = torch.full((fin, fout), float('nan'), device='cuda')
+    gb = torch.full((fout,), float('nan'), device='cuda')
+    L().fc_wgrad(B, fin, fout, dxb.data_ptr(), x_ld, ddy.data_ptr(), y_ld, gm.data_ptr(), gb.data_ptr(), ws.ptr, ws.bytes, stream())
+    assert rel_err(host(gm), rdm) < TOL
+    assert rel_err(host(gb), rdb) < TOL
+
+
+@pytest.mark.parametrize("case", LC.APPFLOW_B64, ids=LC.case_id)
+def test_appflow_layers_at_batch_64(case):
+    """appearance_flow_model.py:88-125 at conf.py:21's batch: the kernels bench.py times."""
+    run_conv_case(case)
+
+
+@pytest.mark.parametrize("case", LC.BASEPRED_B128, ids=LC.case_id)
+def test_base_prediction_layers_at_batch_128(case):
+    """main_model.py:96-137 at BASELINE config 3's batch."""
+    run_conv_case(case)
+
+
+@pytest.mark.parametrize("case", LC.FC_B64 + LC.FC_HIGHDIM, ids=LC.case_id)
+def test_fc_layers_at_benchmark_batch(case):
+    run_fc_case(case)
+
+
+def test_exact_fp32_rung_at_batch_64():
+    """the MV3D_DISABLE=4096 twins (exact fp32 MFMA) of the two layers that carry the step, at the benchmarked batch"""
+    old = L().set_diagnostics(4096)
+    try:
+        run_conv_case(LC.APPFLOW_B64[1])
+        run_conv_case(LC.APPFLOW_B64[14])
+    finally:
+        L().set_diagnostics(old)
+
+
+def test_model_step_at_benchmark_batch():
+    """Whole AppearanceFlowModel at batch 64 (BASELINE config 2, what bench.py times): forward outputs, loss and all 47
+    gradients against the oracle graph on the same inputs and weights -- the product's own plans (prepared-filter cache,
+    side streams), not per-op calls."""
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    from tests.synth import appflow_feeds
+    from tests.test_gpu_model import _perturb_biases, _oracle_at_device_kinks, _rel
+    B = 64
+    model = AppearanceFlowModel({'batch_size': B, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda')
+    g = model.graph
+    names = {o[0] for plan in (g.plan_fwd, g.plan_bwd) for o in _lib.plan_ops(plan)}
+    assert 'bconv_split_all' in names and any(n.startswith('bconvu<5x5,256px') for n in names)
+    variables = _perturb_biases(g)
+    feeds = appflow_feeds(np.random.default_rng(3), B)
+    builder = omodels.appearance_flow_builder('base')
+    out, grads, tape = omodels.run(builder, {k: v.copy() for k, v in variables.items()}, feeds)
+    model.feed(**feeds)
+    g.run_forward()
+    g.run_backward()
+    torch.cuda.synchronize()
+    out, grads, tape = _oracle_at_device_kinks(model, builder, variables, feeds, out, grads, tape)
+    assert _rel(model.flow_field.numpy(), out['flow_field']) < 1e-4
+    assert _rel(model.gen.numpy(), out['gen']) < 1e-4
+    np.testing.assert_allclose(float(g.loss_buf[0]), float(out['loss']), rtol=1e-5)
+    got = g.get_gradients()
+    assert set(got) == set(grads)
+    worst = max(_rel(got[k], grads[k]) for k in grads)
+    assert worst < 1e-3, worst

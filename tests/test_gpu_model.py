@@ -298,6 +298,42 @@ def test_mv3d_models(variant):
     assert np.isfinite(l1) and l1 < l0
 
 
+def test_kink_flips_are_rounding_not_indexing():
+    """The activation-sign override (above) tolerates 8 + 2e-5 * elements flipped signs.  If those flips were an indexing
+    slip rather than rounding at pre-activations of ~0, the exact-fp32 rung (mv3d_set_diagnostics(4096): an fma chain that
+    differs from BLAS only in summation order) would flip as many; it must flip no more than the split-bf16 kernels do,
+    every flipped element must sit within 1e-5 of the layer maximum of zero (asserted inside the override), and with the
+    flips overridden both rungs must agree with the oracle.  Model: the multi-object graph that showed 20 flips in round 1."""
+    from dynamic_multiview_3d_amd.multiobject_appflow import MultiObjectAppFlow
+    from tests.synth import multiobj_feeds
+    conf = {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'gen_sep_images': '', 'fully_conv': '',
+            'batch_size': 2, 'learning_rate': 1e-4}
+    f = multiobj_feeds(np.random.default_rng(5), 2)
+    builder = omodels.multiobject_builder(conf)
+    counts = {}
+    for rung, mask in (('split_bf16', 0), ('exact_fp32', 4096)):
+        old = _lib.lib().set_diagnostics(mask)
+        try:
+            model = MultiObjectAppFlow(conf, load_tfrec=False, device='cuda')
+            g = model.graph
+            variables = _perturb_biases(g)
+            out, grads, tape = omodels.run(builder, {k: v.copy() for k, v in variables.items()}, f)
+            model.feed(**f)
+            g.run_forward()
+            g.run_backward()
+            torch.cuda.synchronize()
+            _, flips = _activation_pattern_override(model, tape)
+            counts[rung] = flips
+            out, grads, tape = _oracle_at_device_kinks(model, builder, variables, f, out, grads, tape)
+            got = g.get_gradients()
+            worst = max(_rel(got[k], grads[k]) for k in grads)
+            assert worst < (1e-3 if mask == 0 else 5e-5), (rung, worst)
+        finally:
+            _lib.lib().set_diagnostics(old)
+    print("flipped activation signs:", counts)
+    assert counts['exact_fp32'] <= max(counts['split_bf16'], 8), counts
+
+
 @pytest.mark.gpu
 def test_fused_head_equals_the_three_launch_head(monkeypatch):
     """Graph._fuse_resample_losses: the appearance-flow head as one launch (sampler + loss + sampler gradient) and as three

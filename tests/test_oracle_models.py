@@ -4,7 +4,7 @@ import pytest
 
 from oracle import models
 from oracle.graph import Tape
-from tests.torch_tape import run_torch
+from oracle.torch_tape import run_torch
 from tests.synth import appflow_feeds, multiobj_feeds
 
 
