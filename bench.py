@@ -9,11 +9,16 @@ A step = one pass of the hot path over one batch: forward, loss, hand-scheduled 
 `appflow_offset`: AppearanceFlowModel, 128x128x3, batch 64 per GPU (weak scaling), synthetic
 car-render-like batches resident in HBM before the timed region, reference initialisers.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step: algorithmic
-FLOPs of its launches (2*N*Ho*Wo*kh*kw*Cin*Cout each) over their HIP-event durations
-measured inside the timed region on the launch stream.  `cpu_baseline` times the numpy oracle
-(CPU restatement of the TF-1.3 graph; TensorFlow itself is unavailable offline) on the host
-cores, on a bounded sample (batch 8).
+Prints ONE JSON line (rank 0).  `roofline` describes the conv / deconv stack -- the kernel family north_star's
+MFMA target is set on -- as ONE aggregate: algorithmic FLOPs of all its launches (2*N*Ho*Wo*kh*kw*Cin*Cout each,
+DESIGN.md; slab reductions, split-K tails and the filter conversion count with 0 FLOPs but their time) over their
+HIP-event durations measured inside the timed region on the streams they are launched on; `roofline.top_kernel`
+is the same for the family's largest single kernel.  `cpu_baseline` times the CPU restatement of the TF-1.3 graph
+(oracle/torch_tape.py on torch's CPU convolution library; TensorFlow itself is unavailable offline) on the host cores:
+batch 8 and batch 64, 3 warm-up + 10 timed steps each, median.
+
+`--gpus N` without a torch.distributed launcher in the environment starts the N rank processes itself (fresh children,
+created before this process touches the GPU) and relays rank 0's JSON line.
 """
 import argparse
 import gc
@@ -38,6 +43,19 @@ PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 def is_split_bf16(label):
     """Kernels that evaluate every fp32 product as three bf16 MFMA products (bconv.hip)."""
     return label.startswith('bconv') or '_b3' in label
+
+
+# conv / deconv family: forward, data-gradient and filter-gradient kernels of conv2d_msra / deconv2d_msra
+# (tf_utils.py:70-98) plus the launches that only exist to serve them (mv3d_plan_profile_select pattern syntax)
+CONV_FAMILY = ('bconv*|wgrad_b3*|wgrad_tile*|hconv*|igemm*|smallc_*|thin_*|filtgrad*|reduce_slabs|transpose_filter')
+
+
+def in_conv_family(label):
+    for pat in CONV_FAMILY.split('|'):
+        if (pat.endswith('*') and label.startswith(pat[:-1])) or label == pat:
+            return True
+    return False
+
 TRAIN_MFLOP_PER_IMAGE_CONV = 3035.6   # BASELINE.md section 2 (fwd + dgrad + wgrad, no dgrad for e0)
 TRAIN_MFLOP_PER_IMAGE_ALL = 3440.0
 
@@ -59,37 +77,68 @@ def synth_batch(rng, b, h=128):
     return dict(image0=imgs(), image1=imgs(), disp=disp)
 
 
-def cpu_baseline(batch=8, steps=3):
-    """numpy oracle (oracle/: CPU restatement of the reference graph) timed on the host cores."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
+def cpu_baseline(batches=(8, 64), warmup=3, steps=10):
+    """the CPU restatement of the TF-1.3 graph (oracle/torch_tape.py: torch CPU ops + autograd, fp32, TF-Adam)
+    on the host cores; configs appflow_firsttry (batch 8) and appflow_offset (batch 64), 3 warm-up + 10 timed steps, median."""
     from oracle import models as omodels
     from oracle.graph import Tape
-    rng = np.random.default_rng(0)
-    feeds = synth_batch(rng, batch)
-    builder = omodels.appearance_flow_builder('base')
-    t = Tape(None, rng=np.random.default_rng(1234))
-    builder(t, {k: t.const(v) for k, v in feeds.items()})          # creates the variables
-    variables, adam = t.vars, omodels.AdamState(1e-4)
-    omodels.step(builder, variables, adam, feeds)                   # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        omodels.step(builder, variables, adam, feeds)
-    dt = time.perf_counter() - t0
-    # threads actually used: the BLAS pool numpy multiplies on (im2col GEMMs dominate), bounded by this process's CPU set
+    from oracle.torch_tape import TorchTrainer
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count()
-    cores = avail
-    try:
-        from threadpoolctl import threadpool_info
-        blas = [i.get('num_threads', 0) for i in threadpool_info() if i.get('user_api') == 'blas']
-        if blas:
-            cores = min(avail, max(blas))
-    except Exception:
-        pass
-    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "numpy/BLAS oracle, AppearanceFlowModel fwd+bwd+Adam, %d timed steps at batch %d after 1 warm-up "
-                      "(TensorFlow 1.3 reference cannot run offline)" % (steps, batch)}
+    threads = max(1, min(avail, torch.get_num_threads()))
+    per_batch = {}
+    for b in batches:
+        feeds = synth_batch(np.random.default_rng(0), b)
+        builder = omodels.appearance_flow_builder('base')
+        t = Tape(None, rng=np.random.default_rng(1234))
+        builder(t, {k: t.const(v) for k, v in feeds.items()})          # creates the variables (reference initialisers)
+        trainer = TorchTrainer(builder, t.vars, lr=1e-4)
+        for _ in range(warmup):
+            trainer.step(feeds)
+        times = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            trainer.step(feeds)
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        per_batch[b] = {"images_per_sec": round(b / times[len(times) // 2], 2), "median_step_s": round(times[len(times) // 2], 4),
+                        "min_step_s": round(times[0], 4)}
+    main_b = batches[-1]
+    return {"value": per_batch[main_b]["images_per_sec"], "unit": "images/sec", "cores": threads, "kind": "port",
+            "cpu_model": _cpu_model(), "cpus_available": avail,
+            "by_batch": {str(b): v for b, v in per_batch.items()},
+            "sample": "CPU restatement of the TF-1.3 graph (oracle/torch_tape.py: torch CPU convolution / matmul kernels + autograd, "
+                      "fp32, TF-Adam; TensorFlow 1.3 itself cannot run offline), AppearanceFlowModel fwd+bwd+Adam, %d warm-up + %d timed "
+                      "steps, median; value = batch %d, batch %d beside it" % (warmup, steps, main_b, batches[0])}
+
+
+def self_launch(args):
+    """`bench.py --gpus N` from a plain shell: start N ranks (one process per GPU) under torch.distributed.run as fresh
+    children -- this process has not touched the GPU -- and exit with their status; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -100,6 +149,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (weak scaling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='do not bracket launches with HIP events')
+    ap.add_argument('--event-every', type=int, default=4, help='steps of the timed region that carry HIP events on the conv/deconv family: every n-th')
     ap.add_argument('--dump-kernels', action='store_true', help='print the per-kernel table to stderr')
     ap.add_argument('--dump-ops', action='store_true', help='print every launch of the step in order to stderr')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -109,9 +159,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -197,12 +248,12 @@ def main():
                 k['ms'] += ms / runs
 
     timing = not args.no_kernel_timing
-    # ---- warm-up (untimed).  With kernel timing on, the warm-up steps after the first run the same launches on one
-    # stream with every launch bracketed by HIP events: that gives the per-kernel table (own durations, shares that
-    # add up) and names the dominant kernel.  The timed region then runs the product's multi-stream train step with
-    # events on that kernel's launches only.
+    # ---- warm-up (untimed).  With kernel timing on, the warm-up steps after the first run the same launches on ONE
+    # stream with every launch bracketed by HIP events: that gives the per-kernel table of OWN durations (shares that add
+    # up; `stack`, `roofline.alone`).  The timed region then runs the product's multi-stream train step; every
+    # `--event-every`-th step of it carries events on the conv / deconv family's launches (and on the optimiser's), on the
+    # streams they are issued on, which is what `roofline` reports.
     table = collections.OrderedDict()
-    dominant = None
     if args.warmup > 0 or timing:
         one_step()
     if timing:
@@ -217,23 +268,20 @@ def main():
         torch.cuda.synchronize()
         collect(table)
         table['adam'] = dict(launches=1, flops=0.0, bytes=28.0 * g.flat_size, ms=adam_collect())
-        dominant = max(table.items(), key=lambda kv: kv[1]['ms'])[0]
     else:
         for _ in range(max(args.warmup - 1, 0)):
             one_step()
-    # ---- timed region: EXACTLY K steps.  Only the dominant kernel's launches carry events (a handful per
-    # step), so `value` and `roofline` come from the same region.
+    # ---- timed region: EXACTLY K steps
     for plan in (g.plan_fwd, g.plan_bwd):
         lib.plan_profile_reset(plan)
-        if timing and dominant is not None and dominant != 'adam':
-            lib.plan_profile_select(plan, dominant.encode())
-            lib.plan_profile(plan, 1)
-        else:
-            lib.plan_profile(plan, 0)
-    # N > 1: the product's step runs Adam bucket by bucket behind the all-reduces on the compute stream; bracketing it there
-    # would need the un-bucketed form, so the timed region carries no events and Adam's duration is the warm-up table's
-    time_adam = timing and dominant == 'adam' and world == 1
+        lib.plan_profile(plan, 0)
+        if timing:
+            lib.plan_profile_select(plan, CONV_FAMILY.encode())
+    every = max(1, args.event_every)
+    # N > 1: the product's step runs Adam bucket by bucket behind the collectives; it carries no events there
+    time_adam = timing and world == 1 and g.overlap_adam
     adam_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if time_adam else []
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     # Host hygiene, as `timeit` does: no cyclic-GC pass inside the timed region.  The launch thread runs ~45 ms ahead of
     # the GPU; a full collection over the interpreter's ~10^6 live objects (triggered by the per-step event objects)
     # stalls it for longer than that and the queues run dry -- measured: 2.6 -> 2.95 ms/step.
@@ -242,8 +290,16 @@ def main():
     gc.disable()
     sync()
     t0 = time.perf_counter()
+    step_ev[0].record()
+    n_evsteps = 0
     for i in range(args.steps):
-        one_step(adam_ev[i] if (time_adam and i % 3 == 0) else None)      # every third step carries the events (each costs a queue barrier)
+        evstep = timing and (i % every == every - 1)
+        if timing:
+            for plan in (g.plan_fwd, g.plan_bwd):
+                lib.plan_profile(plan, 1 if evstep else 0)
+        n_evsteps += int(evstep)
+        one_step(adam_ev[i] if (time_adam and evstep) else None)
+        step_ev[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
     if gc_was_enabled:
@@ -253,16 +309,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     loss = float(g.loss_buf[0])
+    step_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
 
-    # ---- dominant kernel inside the timed region (rank 0's GPU)
+    # ---- the conv / deconv family inside the timed region (rank 0's GPU)
     kern = collections.OrderedDict()
-    if timing and dominant is not None:
-        if time_adam:
-            kern['adam'] = dict(launches=1, flops=0.0, bytes=28.0 * g.flat_size, ms=adam_collect())
-        elif dominant == 'adam':
-            kern['adam'] = dict(table['adam'])
-        else:
+    adam_in_region = None
+    if timing:
+        if n_evsteps:
             collect(kern)
+            if time_adam:
+                adam_in_region = adam_collect()
         for plan in (g.plan_fwd, g.plan_bwd):
             lib.plan_profile(plan, 0)
             lib.plan_profile_select(plan, None)
@@ -283,55 +339,74 @@ def main():
                                 "fp32-MFMA kernels); activations, loss, resampler, Adam and all stored tensors fp32",
                    "launches_per_step": g.n_launch_fwd + g.n_launch_bwd + 1},
         "loss": round(loss, 6),
+        "step_ms": {"mean": round(ms_per_step, 4), "median": round(step_ms[len(step_ms) // 2], 4), "min": round(step_ms[0], 4),
+                    "max": round(step_ms[-1], 4),
+                    "source": "HIP events on the main stream at step boundaries (rank 0); mean = host clock over the region / steps"},
     }
-    if timing and kern and dominant in kern:
-        dom_name, dom = dominant, kern[dominant]
-        if dom['flops'] > 0:
-            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            if is_split_bf16(dom_name):
-                # algorithmic FLOPs against the dense bf16 peak; the kernel executes 3 MFMA FLOPs per algorithmic one
-                roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "mfma_dtype": "bf16 (split: 3 products per f32 product)",
-                        "executed_tflops": round(3 * ach, 2), "frac_executed": round(3 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
-                        "frac_vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
-            else:
-                roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "mfma_dtype": "f32"}
-        else:
-            ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 4)}
+
+    def family(tab):
+        fam = {n: k for n, k in tab.items() if in_conv_family(n)}
+        return fam, sum(k['ms'] for k in fam.values()), sum(k['flops'] for k in fam.values()), sum(k['launches'] for k in fam.values())
+
+    def mfma_rates(flops, ms, b3):
+        ach = flops / (ms * 1e-3) / 1e12
+        if b3:
+            return {"achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "executed_tflops": round(3 * ach, 2), "frac_executed": round(3 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "frac_vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
+        return {"achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
+
+    if timing and table:
         gpu_ms = sum(k['ms'] for k in table.values())
-        roof.update({"launches_per_step": dom['launches'], "avg_launch_ms": round(dom['ms'] / dom['launches'], 5),
-                     "share_of_gpu_time": round(table[dom_name]['ms'] / gpu_ms, 4), "traffic": None,
-                     "measured": ("HIP events around the optimiser launches (their own stream) inside the timed region, on every third step; "
-                                  "the reverse pass runs filter-gradient kernels and Adam on side streams, so a launch shares the GPU with concurrent kernels")
-                                 if time_adam else
-                                 ("HIP events around this kernel's launches inside the timed region (a launch may share the GPU with "
-                                  "side-stream kernels)" if dom_name != 'adam' else
-                                  "HIP events around the optimiser launch of the warm-up steps (N > 1: the timed region runs the product's "
-                                  "bucketed Adam behind the all-reduces and carries no events)")})
-        # the same kernel with the GPU to itself (warm-up table pass, streams serialized): separates kernel quality from the
-        # cost of sharing HBM / CUs with the kernels it overlaps in the product schedule
-        tk = table.get(dom_name)
-        if tk and tk['ms'] > 0:
-            if tk['flops'] > 0:
-                a1, pk = tk['flops'] / (tk['ms'] * 1e-3) / 1e12, roof['peak']
-            else:
-                a1, pk = tk['bytes'] / (tk['ms'] * 1e-3) / 1e9, PEAK_HBM_GBS
-            roof["alone"] = {"avg_launch_ms": round(tk['ms'] / tk['launches'], 5), "achieved": round(a1, 1), "frac": round(a1 / pk, 4),
-                             "measured": "HIP events, warm-up steps, one stream"}
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile):
-            try:
-                ent = json.load(open(tfile)).get(dom_name)
-                if ent:      # HBM bytes per launch from committed rocprofv3 PMC passes (profiles/), FETCH_SIZE x2-corrected
-                    # per launch as counted in `launches_per_step` above (the optimiser is one logical launch here, 4-5 slices in the product)
-                    roof["traffic"] = round(ent["hbm_bytes_per_launch"] * (ent.get("launches_per_step") or dom['launches']) / dom['launches'])
-                    roof["algorithmic_bytes_per_launch"] = round(dom['bytes'] / dom['launches'])
-            except Exception:
-                pass
-        out["roofline"] = roof
+        b3 = out["dtype"] == "bf16x3"
+        src = kern if kern else table
+        fam, fam_ms, fam_fl, fam_n = family(src)
+        tfam, tfam_ms, tfam_fl, _ = family(table)
+        if fam_ms > 0:
+            roof = {"bound": "mfma", "kernel": "conv/deconv stack: all %d launches per step of conv2d / conv2d_transpose forward, data-gradient and "
+                                               "filter-gradient kernels (%s), slab reductions, split-K tails and filter conversion included at 0 FLOP"
+                                               % (fam_n, ", ".join(sorted({n.split('<')[0] for n in fam}))),
+                    "mfma_dtype": "bf16 (split: 3 executed products per algorithmic f32 product)" if b3 else "f32"}
+            roof.update(mfma_rates(fam_fl, fam_ms, b3))
+            roof.update({"launches_per_step": fam_n, "avg_launch_ms": round(fam_ms / max(fam_n, 1), 5), "ms_per_step": round(fam_ms, 4),
+                         "algorithmic_gflop_per_step": round(fam_fl / 1e9, 2),
+                         "share_of_gpu_time": round(tfam_ms / gpu_ms, 4), "traffic": None,
+                         "measured": ("HIP events around every launch of the family inside the timed region, on the stream it is issued on, on every "
+                                      "%d-th step (%d of %d steps); filter-gradient kernels run on a side stream next to the data-gradient kernels and "
+                                      "Adam, so a launch shares the GPU with concurrent kernels" % (every, n_evsteps, args.steps)) if kern else
+                                     "HIP events, warm-up steps, one stream (no event steps inside the timed region)"})
+            if tfam_ms > 0:
+                al = mfma_rates(tfam_fl, tfam_ms, b3)
+                al.update({"ms_per_step": round(tfam_ms, 4), "measured": "HIP events, warm-up steps, all launches on one stream (own durations)"})
+                roof["alone"] = al
+            # largest single kernel of the family (own durations)
+            top = max(((n, k) for n, k in tfam.items() if k['flops'] > 0), key=lambda kv: kv[1]['ms'], default=None)
+            if top is not None:
+                tn, tk = top
+                tr = mfma_rates(tk['flops'], tk['ms'], is_split_bf16(tn))
+                tr.update({"kernel": tn, "launches_per_step": tk['launches'], "avg_launch_ms": round(tk['ms'] / tk['launches'], 5)})
+                if kern.get(tn, {}).get('ms', 0) > 0:
+                    tr["in_timed_region"] = mfma_rates(kern[tn]['flops'], kern[tn]['ms'], is_split_bf16(tn))
+                roof["top_kernel"] = tr
+            tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    famt = tj.get('_family', {}).get('conv')
+                    if famt:      # HBM bytes per step of the family from committed rocprofv3 PMC passes (profiles/), FETCH_SIZE x2-corrected
+                        roof["traffic"] = round(famt["hbm_bytes_per_step"] / max(fam_n, 1))
+                        roof["traffic_per_step"] = famt["hbm_bytes_per_step"]
+                        roof["traffic_source"] = famt.get("source")
+                    roof["algorithmic_bytes_per_step"] = round(sum(k['bytes'] for k in tfam.values()))
+                except Exception:
+                    pass
+            out["roofline"] = roof
+        ad = table.get('adam')
+        if ad and ad['ms'] > 0:
+            out["adam"] = {"bound": "hbm", "algorithmic_bytes": ad['bytes'], "alone_ms": round(ad['ms'], 4),
+                           "alone_gbs": round(ad['bytes'] / (ad['ms'] * 1e-3) / 1e9, 1), "alone_frac_of_hbm_peak": round(ad['bytes'] / (ad['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+            if adam_in_region:
+                out["adam"].update({"in_region_ms": round(adam_in_region, 4), "in_region_gbs": round(ad['bytes'] / (adam_in_region * 1e-3) / 1e9, 1)})
         mfma = {n: k for n, k in table.items() if k['flops'] > 0}
         conv_ms = sum(k['ms'] for k in mfma.values())
         conv_fl = sum(k['flops'] for k in mfma.values())
@@ -347,8 +422,8 @@ def main():
                         "hbm_kernels_share_of_gpu_time": round(hbm_ms / gpu_ms, 4)}
         if args.dump_kernels and rank == 0:
             for n, k in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
-                rate = ("%7.1f TF/s" % (k['flops'] / k['ms'] / 1e9)) if k['flops'] > 0 else ("%7.0f GB/s" % (k['bytes'] / k['ms'] / 1e6))
-                print("%-34s launches=%3d  ms/step=%8.4f  %s" % (n, k['launches'], k['ms'], rate), file=sys.stderr)
+                rate = ("%7.1f TF/s" % (k['flops'] / k['ms'] / 1e9)) if k['flops'] > 0 else ("%7.0f GB/s" % (k['bytes'] / max(k['ms'], 1e-9) / 1e6))
+                print("%-40s launches=%3d  ms/step=%8.4f  %s" % (n, k['launches'], k['ms'], rate), file=sys.stderr)
     # whole step against the roofline the reference's arithmetic implies: algorithmic fp32 FLOPs (3 440 MFLOP per trained
     # image) over wall time, vs the fp32 MFMA peak -- independent of which matrix-core type carries them
     out["step_f32_equivalent"] = {"tflops": round(value / world * TRAIN_MFLOP_PER_IMAGE_ALL * 1e6 / 1e12, 2),

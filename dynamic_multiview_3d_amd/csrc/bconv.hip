@@ -650,8 +650,10 @@ void bconv_set_rows(HconvExtra* x, int stride_h) {
     else if (x->TW == 8 && stride_h == 2 && s2rows) rb = ((rb + 63) & ~127) + 64;     // two halo rows per tile row: 2 * rb = 128 mod 256
     else if (x->TW == 8) rb = ((rb + 127) & ~255) + 128;
     // Pitch search: among the pitches between the bare row and the rule above, the smallest one with the fewest modelled bank
-    // conflicts (never more LDS than the rule, so the workgroups-per-CU plan of the caller still holds).  Needs the full tile
-    // geometry; the size estimate of pick_tile passes only HC / HR / TW and keeps the rule.
+    // conflicts.  For TW >= 8 it never takes more LDS than the rule, so pick_tile's size estimate (which passes only HC / HR / TW
+    // and therefore keeps the rule) is an upper bound of what is launched.  Tiles narrower than 8 pixels may take up to 240 bytes
+    // per halo row MORE than the bare pitch: they only come from the small-image planner (hconv.hip), which calls this function
+    // with the full geometry and sizes LDS, capacity checks and workgroups per CU from bconv_lds_bytes() of the result.
     static const int search = getenv("MV3D_BC_PITCHSEARCH") ? atoi(getenv("MV3D_BC_PITCHSEARCH")) : 1;
     const bool geom = x->TW > 0 && x->img_shift > 0 && (1 << x->tw_shift) == x->TW && (x->G <= 1 || x->HRi > 0);
     if (search && geom) {

@@ -217,12 +217,25 @@ int mv3d_plan_profile_collect(mv3d_plan* p) {
     return MV3D_OK;
 }
 
-// Restrict event bracketing to the launches whose kernel label equals `name` (NULL = all launches).
-// Timing one kernel costs a handful of events per step, so it can stay on inside a timed region.
+// Restrict event bracketing to the launches whose kernel label matches `name` (NULL = all launches): one label, or a
+// '|'-separated list of labels, each optionally ending in '*' (prefix match) -- e.g. "bconv*|wgrad_b3*|reduce_slabs" for
+// the conv / deconv family.  Timing a subset costs a handful of events per step, so it can stay on inside a timed region.
+static bool label_matches(const char* label, const char* pats) {
+    const size_t ll = strlen(label);
+    for (const char* p = pats; *p;) {
+        const char* e = strchr(p, '|');
+        size_t n = e ? (size_t)(e - p) : strlen(p);
+        if (n > 0 && p[n - 1] == '*') { if (ll >= n - 1 && strncmp(label, p, n - 1) == 0) return true; }
+        else if (ll == n && strncmp(label, p, n) == 0) return true;
+        p += n + (e ? 1 : 0);
+    }
+    return false;
+}
+
 int mv3d_plan_profile_select(mv3d_plan* p, const char* name) {
     if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_profile_select: null plan");
     if (p->used) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_profile_select: collect pending runs first");
-    for (auto& o : p->ops) o.selected = (name == nullptr) || (strcmp(o.info.name, name) == 0);
+    for (auto& o : p->ops) o.selected = (name == nullptr) || label_matches(o.info.name, name);
     return MV3D_OK;
 }
 

@@ -535,7 +535,7 @@ int try_fc_stream(bool trans, int B, int in, int out, const void* x, int x_ld, c
     fill_epi(e, epi);
     const int64_t total = (int64_t)B * p.N;
     const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
-    return dispatch(stream, OpInfo{"igemm_splitk_epilogue", 0.0, (double)total * 4.0 * (p.nsplit + 1)}, [=](hipStream_t s) {
+    return dispatch(stream, OpInfo{"fc_splitk_epilogue", 0.0, (double)total * 4.0 * (p.nsplit + 1)}, [=](hipStream_t s) {
         launch_epi(e, blocks, s);
         return launched("igemm_splitk_epilogue");
     });

@@ -858,6 +858,15 @@ class Graph:
         return sd
 
     def load_state_dict(self, sd):
+        missing = [k for k in self.variables if k not in sd]
+        slots = {'beta1_power', 'beta2_power'}
+        unexpected = [k for k in sd if k not in slots and k not in self.variables and
+                      not (k.rsplit('/', 1)[0] in self.variables and k.rsplit('/', 1)[-1] in ('Adam', 'Adam_1'))]
+        bad = [k for k, v in self.variables.items() if k in sd and tuple(sd[k].shape) != tuple(v.shape)]
+        if missing or unexpected or bad or not slots <= set(sd):
+            raise KeyError("checkpoint does not match the model: missing %s; unexpected %s; shape mismatch %s%s"
+                           % (missing[:8], unexpected[:8], [(k, tuple(sd[k].shape), self.variables[k].shape) for k in bad[:8]],
+                              '' if slots <= set(sd) else '; no beta1_power / beta2_power'))
         for k, v in self.variables.items():
             v.value().copy_(sd[k])
             if k + '/Adam' in sd:

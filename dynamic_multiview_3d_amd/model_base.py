@@ -35,7 +35,7 @@ class Saver:
             arrays = tf_checkpoint.read_checkpoint(save_path)
             self.graph.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in arrays.items()})
         elif os.path.isfile(save_path):                      # state dict written by torch.save (pre-bundle snapshots)
-            self.graph.load_state_dict(torch.load(save_path, map_location='cpu'))
+            self.graph.load_state_dict(torch.load(save_path, map_location='cpu', weights_only=True))      # tensors only: never unpickle objects
         else:
             raise FileNotFoundError("no checkpoint at %r (expected %s.index)" % (save_path, save_path))
 

@@ -241,6 +241,10 @@ class TFRecordInput:
 
     def __init__(self, conf, input_shapes, training=True, device='cpu', seed=0, prefetch=4, verify=True, rank=0, world=1):
         self.files = split_files(conf, training)
+        if not self.files:
+            # the reference fails at construction: tf.train.string_input_producer rejects an empty list (read_tf_records.py:42);
+            # e.g. one shard with train_val_split = 0.95 leaves floor(0.95) = 0 training files
+            raise RuntimeError('no files for training=%s after train_val_split=%r of %s' % (training, conf.get('train_val_split'), conf['data_dir']))
         if world > 1:                                    # data parallel: every rank reads its own subset of the shards
             self.files = self.files[rank::world] or self.files
         self.spec = {k: tuple(s[1:]) for k, s in input_shapes.items()}
@@ -288,6 +292,7 @@ class TFRecordInput:
             files = self._files()
             nread = C.c_int(0)
             slot = 0
+            dry = 0                                       # consecutive files that yielded no record
             while not self._stop:
                 bufs, c_dst, done = ring[slot % nring]
                 slot += 1
@@ -300,9 +305,12 @@ class TFRecordInput:
                         lib.tfrecord_open(next(files).encode(), 1 if self.verify else 0, C.byref(reader))
                     lib.tfrecord_read(reader, self.batch - have, have, len(names), c_names, c_kinds, c_sizes, c_dst, C.byref(nread))
                     have += nread.value
+                    dry = 0 if nread.value > 0 else dry + 1
                     if have < self.batch:                 # end of this file
                         lib.tfrecord_close(reader)
                         reader = None
+                        if dry > len(self.files):
+                            raise RuntimeError('a full pass over %d file(s) of %s yielded no record' % (len(self.files), os.path.dirname(self.files[0])))
                 out = {}
                 if cuda:
                     with torch.cuda.stream(stream):

@@ -297,8 +297,11 @@ def write_checkpoint(prefix, tensors):
             f.write(memoryview(raw))
             items.append((name.encode('utf-8'), _entry_proto(a.dtype, shape, offset, a.nbytes, masked_crc32c(raw))))
             offset += a.nbytes
+    # both files appear atomically, data first: a kill between the two steps leaves either the old pair or the new data
+    # file with the OLD index (whose CRCs then fail loudly on restore), never a truncated index (BundleWriter's own order)
+    write_table(prefix + '.index.tempstate', items)
     os.replace(tmp, _data_file(prefix))
-    write_table(prefix + '.index', items)
+    os.replace(prefix + '.index.tempstate', prefix + '.index')
     return prefix
 
 

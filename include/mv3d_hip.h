@@ -225,8 +225,8 @@ int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, vo
  * (formulas in DESIGN.md), the accumulated milliseconds and the number of timed runs. */
 int mv3d_plan_profile(mv3d_plan* p, int enable);
 int mv3d_plan_profile_collect(mv3d_plan* p);
-/* bracket only the launches whose kernel label equals `name` (NULL: all) -- a handful of events per
- * step, cheap enough to leave on inside a timed region */
+/* bracket only the launches whose kernel label matches `name` (NULL: all): one label or a '|'-separated list, each entry
+ * optionally ending in '*' for a prefix match -- a handful of events per step, cheap enough to leave on inside a timed region */
 int mv3d_plan_profile_select(mv3d_plan* p, const char* name);
 int mv3d_plan_profile_reset(mv3d_plan* p);
 int mv3d_plan_op_info(const mv3d_plan* p, int i, const char** name, double* flops, double* bytes,

@@ -189,3 +189,21 @@ def test_native_reader_reports_bad_records(tmp_path):
         read(['image0'], [0], [49152], verify=0)
     with pytest.raises(_lib.Mv3dError, match='cannot open'):
         lib.tfrecord_open(str(tmp_path / 'nope').encode(), 1, C.byref(C.c_void_p()))
+
+
+def test_empty_split_and_empty_shards_fail_instead_of_hanging(tmp_path):
+    """The reference fails at construction on an empty file list (string_input_producer, read_tf_records.py:42); a spinning
+    input thread would hang train.py silently at step 0."""
+    one = tmp_path / 'one'
+    one.mkdir()
+    with R.TFRecordWriter(str(one / '0.tfrecords')) as w:
+        pass                                                     # a shard with zero records
+    conf = {'data_dir': str(one), 'train_val_split': 0.95, 'batch_size': 2}
+    with pytest.raises(RuntimeError, match='no files for training=True'):        # floor(0.95 * 1) = 0 training files
+        R.TFRecordInput(conf, SHAPES, training=True, device='cpu')
+    with pytest.raises(RuntimeError, match='no files for training=False'):
+        R.TFRecordInput({**conf, 'train_val_split': 1.0}, SHAPES, training=False, device='cpu')
+    inp = R.TFRecordInput({**conf, 'test_mode': True}, SHAPES, device='cpu')     # the only file holds no record
+    with pytest.raises(RuntimeError, match='yielded no record'):
+        inp.next()
+    inp.close()
