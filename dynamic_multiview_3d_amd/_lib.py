@@ -89,6 +89,7 @@ OTHER_FUNCS = {
     "mv3d_plan_create": (_vp, []),
     "mv3d_plan_destroy": (None, [_vp]),
     "mv3d_plan_size": (_i, [_vp]),
+    "mv3d_debug_cconv_stamps": (_i, [_vp, _sz]),
 }
 EXPORTS = sorted(list(STATUS_FUNCS) + list(OTHER_FUNCS))
 

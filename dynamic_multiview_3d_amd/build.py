@@ -14,6 +14,7 @@ UNITS = {
     "conv.hip": [],
     "hconv.hip": [],
     "bconv.hip": [],
+    "cconv.hip": [],
     "wgrad_tile.hip": [],
     "fc.hip": [],
     "elem.hip": ["-ffp-contract=off"],

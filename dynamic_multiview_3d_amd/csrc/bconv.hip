@@ -748,6 +748,7 @@ static int launch_bconv_cfg(const IgemmParams& p, const HconvExtra& x, int nph_f
                             const uint4* wf, int ntiles, void* stream, const char* name, const char* who, double flops, double bytes) {
 #define MV3D_BC(NPH_, MT_, NT_, W_) launch_bconv_t<NPH_, MT_, NT_, W_>(p, x, grid, lds, wf, ntiles, stream, name, who, flops, bytes)
     const int ntaps_all = p.tap_begin[p.so_h * p.so_w];
+    if (WAVES == 8) return launch_cconv(p, x, wf, ntiles, stream, who, flops, bytes);      // pipelined kernel (cconv.hip); planned in hconv.hip
     if (nph_fused == 1 && !x.phase_split && p.so_h == 1 && p.so_w == 1 && (ntaps_all == 25 || ntaps_all == 9) && !(disabled_paths() & 8192)) {
         // wave-specialised pipeline (two halo buffers + accumulator tile in LDS).  OPT-IN (MV3D_DISABLE bit 15): measured
         // 3-5 % slower than bconvu on the 64x64x32 layers -- with one multiplying wave per SIMD the tap loop runs at ~2/3

@@ -74,6 +74,11 @@ void bconv_set_rows(HconvExtra* x, int stride_h = 1);
 int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid,
                  void* wfrag, void* stream, const char* name, const char* who, double flops, double bytes);
 
+// cconv.hip: software-pipelined split-bf16 convolution (one persistent 8-wave workgroup per CU, LDS-DMA halo staging) for
+// single-phase stride-1 5x5 / 3x3 problems on images of at least 16 x 16 pixels
+bool cconv_eligible(const IgemmParams& p, int* kw_out, bool* rev_out);
+int launch_cconv(const IgemmParams& p, const HconvExtra& x, const void* wf, int ntiles, void* stream, const char* who, double flops, double bytes);
+
 int try_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* dM, void* db, void* stream, const char* who);
 
 }  // namespace mv3d

@@ -595,7 +595,17 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
             HconvExtra bx = {};
             int MT = 0, NT = 1, WAVES = 4, fused = nph;
             const char* name = nullptr;
-            if (nph == 1) {
+            int ckw = 0; bool crev = false;
+            static int cc_min = -1;
+            if (cc_min < 0) { const char* e = getenv("MV3D_CC_MINTILES"); cc_min = e ? atoi(e) : 48; }
+            const int ctiles = p.N * cdiv(Hp, 16) * cdiv(Wp, 16);
+            if (nph == 1 && !(disabled_paths() & 1048576) && cconv_eligible(p, &ckw, &crev) && ctiles * cdiv(p.Cc, 32) >= cc_min) {
+                // pipelined kernel (cconv.hip): 16 x 16 tiles x 32 filters, one persistent workgroup per CU
+                bx.TH = 16; bx.TW = 16; bx.tw_shift = 4; bx.img_shift = 8;
+                bx.tiles_h = cdiv(Hp, 16); bx.tiles_w = cdiv(Wp, 16);
+                bx.HR = 15 + ckw; bx.HC = 20; bx.G = 1; bx.HRi = bx.HR; bx.ksplit = 1;
+                MT = 2; NT = 1; WAVES = 8; name = "cconv";
+            } else if (nph == 1) {
                 struct Cand { int pix, MT, NT, WAVES; const char* name; };
                 const int n2 = p.Cc > 32 ? 2 : 1;
                 const Cand ladder[6] = {{256, 2, n2, 4, n2 == 2 ? "bconv<1ph,256px,N64>" : "bconv<1ph,256px,N32>"}, {256, 2, 1, 4, "bconv<1ph,256px,N32>"},

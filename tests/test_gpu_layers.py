@@ -175,7 +175,7 @@ def test_model_step_at_benchmark_batch():
     model = AppearanceFlowModel({'batch_size': B, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda')
     g = model.graph
     names = {o[0] for plan in (g.plan_fwd, g.plan_bwd) for o in _lib.plan_ops(plan)}
-    assert 'bconv_split_all' in names and any(n.startswith('bconvu<5x5,256px') for n in names)
+    assert 'bconv_split_all' in names and any(n.startswith('cconv<5x5,256px') for n in names)
     variables = _perturb_biases(g)
     feeds = appflow_feeds(np.random.default_rng(3), B)
     builder = omodels.appearance_flow_builder('base')
