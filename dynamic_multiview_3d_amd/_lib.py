@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmv3d_hip.so")
+LIB_PATH = os.environ.get("MV3D_LIB") or os.path.join(HERE, "libmv3d_hip.so")      # MV3D_LIB: an experiment build (tools/build_variant.py)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, 'none': ACT_NONE, 'lrelu': ACT_LRELU, 'relu': ACT_RELU, 'tanh': ACT_TANH}

@@ -14,7 +14,7 @@ UNITS = {
     "conv.hip": [],
     "hconv.hip": [],
     "bconv.hip": [],
-    "cconv.hip": [],
+    "cconv.hip": (["-DCC_TAP_STAMPS"] if os.environ.get("MV3D_CC_TAP_STAMPS") else []),
     "wgrad_tile.hip": [],
     "fc.hip": [],
     "elem.hip": ["-ffp-contract=off"],

@@ -271,6 +271,8 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
 #pragma unroll
     for (int u = 0; u < D; ++u) load_b(ring[u], u, 0);
     cbarrier();                                                        // stage 0 is in buffer 0
+    const bool st = (x.dbg & 32) != 0;
+    int stk = 0;
 
     // one stage = NTAPS taps on one 32-channel chunk of one tile; PEND: the previous tile's outputs leave inside the tap loop
     auto stage_body = [&](int s, auto pend_tag) {
@@ -295,6 +297,9 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             for (int sk = 0; sk < 2; ++sk) read_a(0, m, sk);
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
+#ifdef CC_TAP_STAMPS
+            if (t % 6 == 0) cstamp(st, wave, lane, stk);
+#endif
             if constexpr (PEND) {
 #pragma unroll
                 for (int g8 = 0; g8 < 8; ++g8)
@@ -303,6 +308,9 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             {   // look-ahead tap: this chunk, or the first taps of the next stage's chunk
                 const int tn = t + D;
                 const int ccn = cc + 1 < chunks ? cc + 1 : 0;
+#ifdef CC_EXP_NOB
+                if (s == 0 && t < 2)
+#endif
                 load_b(ring[tn % U], tn < NTAPS ? tn : tn - NTAPS, tn < NTAPS ? cc : ccn);
             }
             __builtin_amdgcn_sched_barrier(0);                         // keep the look-ahead load here (hipcc sinks it to its first use)
@@ -318,7 +326,9 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
                     // refill this operand pair for the next tap right here: nine MFMAs (~290 cycles) lie between this read and its
                     // first use; pinned, because hipcc otherwise sinks the reads down to their uses
+#ifndef CC_EXP_NOA
                     if (t + 1 < NTAPS) read_a(t + 1 < NTAPS ? t + 1 : t, m, sk);
+#endif
                     if constexpr (PEND) {
                         if (sk == 0 && m == 1) {
 #pragma unroll
@@ -332,14 +342,12 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
     };
 
     bool pending = false;
-    const bool st = (x.dbg & 32) != 0;
-    int sk = 0;
-    cstamp(st, wave, lane, sk);                                        // 0: first stage starts
+    cstamp(st, wave, lane, stk);                                        // 0: first stage starts
     for (int s = 0; s < nstages; ++s) {
         const int cc = s % chunks;
         if (pending && cc == 0) { stage_body(s, std::true_type{}); pending = false; }
         else stage_body(s, std::false_type{});
-        cstamp(st, wave, lane, sk);                                    // 1 + 2s: taps done
+        cstamp(st, wave, lane, stk);                                    // 1 + 2s: taps done
         if (cc == chunks - 1) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) prev[m] = acc[m];
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             pending = true;
         }
         cbarrier();
-        cstamp(st, wave, lane, sk);                                    // 2 + 2s: barrier passed
+        cstamp(st, wave, lane, stk);                                    // 2 + 2s: barrier passed
     }
     if (pending) {
 #pragma unroll

@@ -38,13 +38,8 @@ def load_conf(conf_file):
     bare module names resolved to this package."""
     if not os.path.exists(conf_file):
         sys.exit("Experiment configuration not found")
-    pkg = 'dynamic_multiview_3d_amd'
-    for name in _ALIASES:
-        sys.modules.setdefault(name, importlib.import_module(pkg + '.' + name))
-    if 'dyn_mult_view' not in sys.modules:         # confs compute data_dir from dyn_mult_view.__file__
-        shim = types.ModuleType('dyn_mult_view')
-        shim.__file__ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'dyn_mult_view', '__init__.py')
-        sys.modules['dyn_mult_view'] = shim
+    from . import compat
+    compat.install()                               # bare model-module names and dyn_mult_view.* (confs use dyn_mult_view.__file__)
     spec = importlib.util.spec_from_file_location('hyperparams', conf_file)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -152,3 +152,23 @@ def test_train_driver_loads_reference_style_conf(lib, tmp_path):
     from dynamic_multiview_3d_amd.main_model import Base_Prediction_Model
     assert train.select_model(conf) is Base_Prediction_Model                     # train.py:57-60
     assert (train.VAL_INTERVAL, train.SAVE_INTERVAL) == (500, 10000)
+
+
+def test_reference_module_paths_resolve_to_this_package():
+    """`dyn_mult_view` with the reference's module paths and class names (appearance_flow_model.py:5,
+    train.py:9, the conf files' bare imports)."""
+    import importlib
+    import dyn_mult_view
+    from dyn_mult_view.mv3d.utils.tf_utils import conv2d_msra, deconv2d_msra, linear_msra, lrelu, resample_layer, warp_pts_layer  # noqa: F401
+    from dyn_mult_view.multi_view_model.appearance_flow_model import AppearanceFlowModel
+    from dyn_mult_view.multi_view_model.main_model import Base_Prediction_Model
+    from dyn_mult_view.multi_view_model.multiobject_appflow import MultiObjectAppFlow  # noqa: F401
+    from dyn_mult_view.multi_view_model.utils.read_tf_records import build_tfrecord_input  # noqa: F401
+    import dynamic_multiview_3d_amd.appearance_flow_model as ours
+    assert AppearanceFlowModel is ours.AppearanceFlowModel
+    assert importlib.import_module('appearance_flow_model') is ours                    # conf files: `from appearance_flow_model import ...`
+    assert importlib.import_module('dyn_mult_view.multi_view_model.train').main
+    assert dyn_mult_view.__file__.endswith('dyn_mult_view/__init__.py')              # confs derive data_dir from it
+    assert Base_Prediction_Model.__module__ == 'dynamic_multiview_3d_amd.main_model'
+    with pytest.raises(ImportError):
+        importlib.import_module('dyn_mult_view.collect_data')                          # out of scope stays unresolved
