@@ -58,6 +58,9 @@ STATUS_FUNCS = {
     "mv3d_u8_to_unit_f32": [_i64, _vp, _vp, _vp],
     "mv3d_fill": [_vp, _i64, _f, _vp],
     "mv3d_adam_step": [_i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _f, _vp],
+    "mv3d_adam_step_dev": [_i64, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_i64), C.POINTER(_i64), _vp],
+    "mv3d_adam_advance": [_vp, _vp],
+    "mv3d_fc_wgrad_adam": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "mv3d_filter_cache_bind": [_G, _i, _vp, _vp, _sz],
     "mv3d_filter_cache_commit": [_vp, _sz, _vp],
     "mv3d_filter_cache_refresh": [_vp],
@@ -89,6 +92,7 @@ OTHER_FUNCS = {
     "mv3d_plan_create": (_vp, []),
     "mv3d_plan_destroy": (None, [_vp]),
     "mv3d_plan_size": (_i, [_vp]),
+    "mv3d_fc_wgrad_adam_supported": (_i, [_i, _i, _i, _i, _i]),
     "mv3d_debug_cconv_stamps": (_i, [_vp, _sz]),
 }
 EXPORTS = sorted(list(STATUS_FUNCS) + list(OTHER_FUNCS))

@@ -315,6 +315,30 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             }
             __builtin_amdgcn_sched_barrier(0);                         // keep the look-ahead load here (hipcc sinks it to its first use)
             const BSet& f = ring[t % U];
+#ifdef CC_EXP_ILV
+            // the two pixel groups' accumulator chains interleaved: consecutive MFMAs never depend on each other
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                const cbf16x8 bh = __builtin_bit_cast(cbf16x8, f.b[sk][0]), bl = __builtin_bit_cast(cbf16x8, f.b[sk][1]);
+                const cbf16x8 ah0 = __builtin_bit_cast(cbf16x8, a[0][sk][0]), al0 = __builtin_bit_cast(cbf16x8, a[0][sk][1]);
+                const cbf16x8 ah1 = __builtin_bit_cast(cbf16x8, a[1][sk][0]), al1 = __builtin_bit_cast(cbf16x8, a[1][sk][1]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1], 0, 0, 0);
+                if (t + 1 < NTAPS) { read_a(t + 1 < NTAPS ? t + 1 : t, 0, sk); read_a(t + 1 < NTAPS ? t + 1 : t, 1, sk); }
+                if constexpr (PEND) {
+                    if (sk == 0) {
+#pragma unroll
+                        for (int g8 = 0; g8 < 8; ++g8)
+                            if (t == ts_of(g8)) fin_group(g8);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
@@ -338,6 +362,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
         }
     };
 

@@ -1622,6 +1622,18 @@ int mv3d_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* d
     }
     return filtgrad(&g, x, dy, dM, db, ws, wsb, stream, "mv3d_fc_wgrad");
 }
+int mv3d_fc_wgrad_adam(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* M, void* adam_m, void* adam_v,
+                       void* db, const void* adam_state, void* stream) {
+    if (B <= 0 || in <= 0 || out <= 0 || !x || !dy || !M || !adam_m || !adam_v || !adam_state || x_ld < in || dy_ld < out)
+        return fail(MV3D_E_INVAL, "mv3d_fc_wgrad_adam: bad arguments");
+    int rc = try_fc_wgrad_adam(B, in, out, x, x_ld, dy, dy_ld, M, adam_m, adam_v, db, adam_state, stream, "mv3d_fc_wgrad_adam");
+    if (rc == 1) return fail(MV3D_E_UNSUPPORTED, "mv3d_fc_wgrad_adam: %d x %d x %d is not a layer of the fused kernel (use mv3d_fc_wgrad + mv3d_adam_step_dev)", B, in, out);
+    return rc;
+}
+int mv3d_fc_wgrad_adam_supported(int B, int in, int out, int x_ld, int dy_ld) {
+    if (is_small_fc(B, in, out)) return 0;
+    return !(B < 2 || in < 64 || out < 64 || (disabled_paths() & (16 | 4096)) || in % 4 || out % 4 || x_ld % 4 || dy_ld % 4);
+}
 size_t mv3d_fc_workspace_bytes(int B, int in, int out) {
     mv3d_conv_geom g; fc_geom(g, B, in, out, in, out);
     size_t a = mv3d_conv_workspace_bytes(&g);

@@ -80,5 +80,7 @@ bool cconv_eligible(const IgemmParams& p, int* kw_out, bool* rev_out);
 int launch_cconv(const IgemmParams& p, const HconvExtra& x, const void* wf, int ntiles, void* stream, const char* who, double flops, double bytes);
 
 int try_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* dM, void* db, void* stream, const char* who);
+int try_fc_wgrad_adam(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* P, void* M1, void* V2, void* db,
+                      const void* state, void* stream, const char* who);
 
 }  // namespace mv3d

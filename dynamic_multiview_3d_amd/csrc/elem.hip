@@ -330,6 +330,41 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t count, float* __restr
     }
 }
 
+// Same pass with the scalars taken from the device Adam state (so that a recorded plan replays with the current step's
+// bias correction) and up to MV3D_ADAM_MAX_SKIP index ranges left untouched (parameters whose update is fused elsewhere).
+struct AdamSkips { int n; int64_t lo[8], hi[8]; };
+__global__ __launch_bounds__(256) void adam_dev_kernel(int64_t count, float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v, const float* __restrict__ st, const AdamSkips sk) {
+    const float lr = st[0], b1 = st[1], b2 = st[2], eps = st[3], b1p = st[4], b2p = st[5], gscale = st[6];
+    const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+    // walk the KEPT float4s only: kept index j -> position by adding the lengths of the skipped ranges that start at or before it
+    // (ranges are sorted and disjoint: the host checks)
+    int64_t kept = count >> 2;
+    for (int r = 0; r < sk.n; ++r) kept -= (sk.hi[r] - sk.lo[r]) >> 2;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < kept; j += (int64_t)gridDim.x * 256) {
+        int64_t i = j;
+        for (int r = 0; r < sk.n; ++r)
+            if (i >= (sk.lo[r] >> 2)) i += (sk.hi[r] - sk.lo[r]) >> 2;
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ge[k] * gscale;
+            me[k] += (gk - me[k]) * omb1;
+            ve[k] += (gk * gk - ve[k]) * omb2;
+            pe[k] -= (me[k] * alpha) / (sqrtf(ve[k]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+__global__ void adam_advance_kernel(float* st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st[4] = st[4] * st[1]; st[5] = st[5] * st[2]; }      // beta_power *= beta, in fp32 like TF's update op
+}
+
 // ---------------------------------------------------------------- activations / copies
 __global__ __launch_bounds__(256) void act_fwd_kernel(int64_t rows, int ch, const float* x, int x_ld, float* y, int y_ld,
                                                      int act, float leak) {
@@ -504,6 +539,36 @@ int mv3d_adam_step(int64_t count, void* p, const void* g, void* m, void* v, floa
     return dispatch(stream, OpInfo{"adam", 0.0, 28.0 * count}, [=](hipStream_t s) {
         adam_kernel<<<blocks, 256, 0, s>>>(count, (float*)p, (const float*)g, (float*)m, (float*)v, alpha, omb1, omb2, eps, grad_scale);
         return launched("adam_kernel");
+    });
+}
+
+int mv3d_adam_step_dev(int64_t count, void* p, const void* g, void* m, void* v, const void* state, int nskip, const int64_t* skip_lo,
+                       const int64_t* skip_hi, void* stream) {
+    if (count <= 0 || (count & 3) || !p || !g || !m || !v || !state) return fail(MV3D_E_INVAL, "mv3d_adam_step_dev: bad arguments (count must be a multiple of 4)");
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(MV3D_E_INVAL, "mv3d_adam_step_dev: buffers must be 16-byte aligned");
+    if (nskip < 0 || nskip > 8 || (nskip > 0 && (!skip_lo || !skip_hi))) return fail(MV3D_E_INVAL, "mv3d_adam_step_dev: at most 8 skipped ranges");
+    AdamSkips sk = {};
+    sk.n = nskip;
+    int64_t skipped = 0;
+    for (int r = 0; r < nskip; ++r) {
+        if ((skip_lo[r] & 3) || (skip_hi[r] & 3) || skip_lo[r] < 0 || skip_hi[r] > count || skip_lo[r] > skip_hi[r])
+            return fail(MV3D_E_INVAL, "mv3d_adam_step_dev: skipped range %d is not a multiple-of-4 sub-range", r);
+        if (r > 0 && skip_lo[r] < skip_hi[r - 1]) return fail(MV3D_E_INVAL, "mv3d_adam_step_dev: skipped ranges must be sorted and disjoint");
+        sk.lo[r] = skip_lo[r]; sk.hi[r] = skip_hi[r];
+        skipped += skip_hi[r] - skip_lo[r];
+    }
+    const int blocks = (int)std::min<int64_t>(cdiv64((count - skipped) / 4 + 1, 256), 4096);
+    return dispatch(stream, OpInfo{"adam", 0.0, 28.0 * (count - skipped)}, [=](hipStream_t s) {
+        adam_dev_kernel<<<blocks, 256, 0, s>>>(count, (float*)p, (const float*)g, (float*)m, (float*)v, (const float*)state, sk);
+        return launched("adam_dev_kernel");
+    });
+}
+
+int mv3d_adam_advance(void* state, void* stream) {
+    if (!state) return fail(MV3D_E_INVAL, "mv3d_adam_advance: null state");
+    return dispatch(stream, OpInfo{"adam_advance", 0.0, 16.0}, [=](hipStream_t s) {
+        adam_advance_kernel<<<1, 64, 0, s>>>((float*)state);
+        return launched("adam_advance_kernel");
     });
 }
 

@@ -284,7 +284,18 @@ struct FcWgradParams {
     const float* X; const float* DY; float* dW; float* db;
     int B, C, K, x_ld, dy_ld;
     int ktiles;
+    // fused optimiser (mv3d_fc_wgrad_adam): dW is the PARAMETER matrix, updated in place from the accumulators
+    float* M1; float* V2;            // Adam slots of the matrix
+    const float* state;              // device Adam state (include/mv3d_hip.h: MV3D_ADAM_*)
 };
+
+// TF ApplyAdam on one element, the arithmetic of adam_kernel (elem.hip) operation for operation (no contraction)
+__device__ __forceinline__ void adam_elem(float g, float& pv, float& mv, float& vv, float alpha, float omb1, float omb2, float eps) {
+#pragma clang fp contract(off)
+    mv += (g - mv) * omb1;
+    vv += (g * g - vv) * omb2;
+    pv -= (mv * alpha) / (sqrtf(vv) + eps);
+}
 
 __global__ __launch_bounds__(256) void fc_wgrad_kernel(const FcWgradParams p) {
     __shared__ __attribute__((aligned(16))) float xs[64 * 128];
@@ -368,6 +379,7 @@ __device__ __forceinline__ uint2 ftr_read(const unsigned char* lds_ptr) {
 // are needed as "8 consecutive batch rows of one column" per lane while the panels arrive row-major, so they
 // are staged as bf16 hi / lo planes [32 b][128 columns] (320-byte rows: 4 consecutive rows x 32 B land on
 // distinct banks) and fetched with the transposing ds_read_b64_tr_b16.
+template <bool ADAM>
 __global__ __launch_bounds__(256) void fc_wgrad_b3_kernel(const FcWgradParams p) {
     constexpr int RS = 320;
     __shared__ __attribute__((aligned(16))) unsigned char xs[2][32 * RS];      // [hi, lo]
@@ -443,15 +455,48 @@ __global__ __launch_bounds__(256) void fc_wgrad_b3_kernel(const FcWgradParams p)
                 }
         }
     }
+    float alpha = 0.f, omb1 = 0.f, omb2 = 0.f, eps = 0.f, gscale = 1.f;
+    if constexpr (ADAM) {
+        const float lr = p.state[0], b1 = p.state[1], b2 = p.state[2], b1p = p.state[4], b2p = p.state[5];
+        eps = p.state[3]; gscale = p.state[6];
+        {
+#pragma clang fp contract(off)
+            alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+            omb1 = 1.0f - b1; omb2 = 1.0f - b2;
+        }
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int k = k0 + wt * 64 + t * 32 + li;
+            if constexpr (ADAM) {
+                // the gradient never goes to HBM: parameter and slots are read, updated and written back here, four rows in
+                // flight per lane (12 loads before the first store)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + ws * 64 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (c < p.C && k < p.K) p.dW[(int64_t)c * p.K + k] = acc[s][t][r];
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    float pv[4], mv[4], vv[4];
+                    int64_t idx[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = c0 + ws * 64 + s * 32 + j + 8 * r4 + 4 * lh;
+                        ok[j] = c < p.C && k < p.K;
+                        idx[j] = ok[j] ? (int64_t)c * p.K + k : 0;
+                        pv[j] = p.dW[idx[j]]; mv[j] = p.M1[idx[j]]; vv[j] = p.V2[idx[j]];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        adam_elem(acc[s][t][4 * r4 + j] * gscale, pv[j], mv[j], vv[j], alpha, omb1, omb2, eps);
+                        if (ok[j]) { p.dW[idx[j]] = pv[j]; p.M1[idx[j]] = mv[j]; p.V2[idx[j]] = vv[j]; }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = c0 + ws * 64 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (c < p.C && k < p.K) p.dW[(int64_t)c * p.K + k] = acc[s][t][r];
+                }
             }
         }
     if (p.db && ct == 0) {
@@ -544,13 +589,29 @@ int try_fc_stream(bool trans, int B, int in, int out, const void* x, int x_ld, c
 int try_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* dM, void* db, void* stream, const char* who) {
     if (B < 2 || in < 64 || out < 64 || (disabled_paths() & 16)) return 1;
     if (in % 4 || out % 4 || x_ld % 4 || dy_ld % 4 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return 1;
-    FcWgradParams p = {(const float*)x, (const float*)dy, (float*)dM, (float*)db, B, in, out, x_ld, dy_ld, cdiv(out, 128)};
+    FcWgradParams p = {(const float*)x, (const float*)dy, (float*)dM, (float*)db, B, in, out, x_ld, dy_ld, cdiv(out, 128), nullptr, nullptr, nullptr};
     const int items = cdiv(in, 128) * p.ktiles;         // one workgroup per 128 x 128 tile
     const double flops = 2.0 * B * (double)in * out, bytes = 4.0 * ((double)in * out + (double)B * (in + out));
     const bool b3 = !(disabled_paths() & 4096);
     return dispatch(stream, OpInfo{b3 ? "fc_wgrad_b3" : "fc_wgrad", flops, bytes}, [=](hipStream_t s) {
-        if (b3) fc_wgrad_b3_kernel<<<items, 256, 0, s>>>(p);
+        if (b3) fc_wgrad_b3_kernel<false><<<items, 256, 0, s>>>(p);
         else fc_wgrad_kernel<<<items, 256, 0, s>>>(p);
+        return launched(who);
+    });
+}
+
+// Filter gradient of a large fc layer with tf.train.AdamOptimizer's update of that matrix fused into the epilogue: returns 1 when
+// the layer is not one the matrix-core kernel takes (the caller then runs mv3d_fc_wgrad + mv3d_adam_step_dev)
+int try_fc_wgrad_adam(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* P, void* M1, void* V2, void* db,
+                      const void* state, void* stream, const char* who) {
+    if (B < 2 || in < 64 || out < 64 || (disabled_paths() & (16 | 4096))) return 1;
+    if (in % 4 || out % 4 || x_ld % 4 || dy_ld % 4 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return 1;
+    FcWgradParams p = {(const float*)x, (const float*)dy, (float*)P, (float*)db, B, in, out, x_ld, dy_ld, cdiv(out, 128), (float*)M1, (float*)V2, (const float*)state};
+    const int items = cdiv(in, 128) * p.ktiles;
+    // algorithmic bytes: p, m, v read and written once (24 B per parameter), operands once
+    const double flops = 2.0 * B * (double)in * out, bytes = 24.0 * (double)in * out + 4.0 * (double)B * (in + out);
+    return dispatch(stream, OpInfo{"fc_wgrad_adam_b3", flops, bytes}, [=](hipStream_t s) {
+        fc_wgrad_b3_kernel<true><<<items, 256, 0, s>>>(p);
         return launched(who);
     });
 }

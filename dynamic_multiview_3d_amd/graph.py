@@ -285,14 +285,33 @@ class LinearNode(Node):
         if not y.grad_written:
             return
         _ensure_premasked(g, y)
+        B, fin, fout = x.shape[0], x.C, y.C
+        if g._fusing and g.lib.fc_wgrad_adam_supported(B, fin, fout, x.ld, y.ld):
+            # Single-GPU step: the matrix gradient never goes to HBM -- ApplyAdam runs in the epilogue of the filter-gradient
+            # kernel (mv3d_fc_wgrad_adam).  It rewrites the matrix, so it is recorded BEHIND the layer's data gradient (the
+            # last reader of the old weights; the side stream forks after it); the bias gradient takes the ordinary path.
+            if x.requires_grad:
+                epi = _epi(mask_of=x)
+                g.lib.fc_dgrad(B, fin, fout, y.grad_ptr, y.ld, self.m.ptr, x.grad_ptr, x.ld, C.byref(epi), g.ws_ptr, g.ws_bytes, g.stream)
+                _note_grad_written(x, x.act != ACT_NONE)
+            def emit(g=g, self=self, x=x, y=y, B=B, fin=fin, fout=fout):
+                g.begin_side(60.0, 0.0, cls=2)          # its own stream: 400 MB of HBM traffic must not hold up the conv filter gradients
+                off = 4 * self.m.offset
+                g.lib.fc_wgrad_adam(B, fin, fout, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.ptr, g.adam_m.data_ptr() + off,
+                                    g.adam_v.data_ptr() + off, self.b.grad_ptr, g.adam_state.data_ptr(), g.stream)
+                g.end_side()
+            g._deferred.append([g.fcadam_delay, emit])
+            g._fused_vars.append(self.m)
+            self.m.has_grad = self.b.has_grad = True
+            return
         ws_side = g.begin_side(25.0, 32.0 if x.requires_grad else 0.0)
-        g.lib.fc_wgrad(x.shape[0], x.C, y.C, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
+        g.lib.fc_wgrad(B, fin, fout, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
                        ws_side, g.ws_bytes, g.stream)
         g.end_side()
         self.m.has_grad = self.b.has_grad = True
         if x.requires_grad:
             epi = _epi(mask_of=x)
-            g.lib.fc_dgrad(x.shape[0], x.C, y.C, y.grad_ptr, y.ld, self.m.ptr, x.grad_ptr, x.ld, C.byref(epi),
+            g.lib.fc_dgrad(B, fin, fout, y.grad_ptr, y.ld, self.m.ptr, x.grad_ptr, x.ld, C.byref(epi),
                            g.ws_ptr, g.ws_bytes, g.stream)
             _note_grad_written(x, x.act != ACT_NONE)
 
@@ -446,7 +465,13 @@ class Graph:
         self.stream = None
         self.ws = None
         self.ws_ptr, self.ws_bytes = None, 0
-        self.n_side = max(0, min(4, int(os.environ.get('MV3D_SIDE_STREAMS', '1'))))      # 0: single-stream reverse pass
+        self.n_side = max(0, min(4, int(os.environ.get('MV3D_SIDE_STREAMS', '2'))))      # 0: single-stream reverse pass; class 1 conv filter gradients, class 2 fused fc optimiser
+        # fused fc optimiser launches are recorded this many graph nodes after their layer's data gradient (0 = right behind it;
+        # default: at the end of the reverse pass).  They stream 400 MB each: next to the other fc layers' weight streams and the
+        # latency-bound 8x8 / 4x4 convolutions they only fight for HBM, next to the MFMA-bound tail of the filter-gradient chain
+        # they are free (measured at B = 64: 0 -> 26.56k, 6 -> 26.65k, end -> 26.83k images/s; unfused bucketed Adam 26.03k)
+        self.fcadam_delay = int(os.environ.get('MV3D_FCADAM_DELAY', '1000000'))
+        self._deferred = []
         self.ws_side = []
         self.side_streams = None
         self._side_rr = 0
@@ -455,6 +480,11 @@ class Graph:
         self.adam_stream = None
         self.adam_timing = None         # list of (start, end) events per optimiser launch when a bench wants them
         self.overlap_adam = os.environ.get('MV3D_OVERLAP_ADAM', '1') != '0'
+        self.fuse_fc_adam = os.environ.get('MV3D_FUSE_FC_ADAM', '1') != '0'      # single-GPU step: Adam of the fc matrices inside their filter-gradient kernels
+        self._fusing = False
+        self._fused_vars = []
+        self.plan_bwd_fused = None
+        self.adam_state = None
         self.plan_fwd = self.plan_bwd = None
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
         self.beta1_power = np.float32(self.beta1)
@@ -534,6 +564,7 @@ class Graph:
         self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.adam_state = torch.zeros(8, dtype=torch.float32, device=dev)      # include/mv3d_hip.h MV3D_ADAM_*
         self.loss_buf = torch.zeros(4, dtype=torch.float32, device=dev)
         self.zero_buf = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.zero_ptr = self.zero_buf.data_ptr()
@@ -618,6 +649,7 @@ class Graph:
             self._emit_losses(with_grad=True)
         finally:
             lib.plan_end()
+        flags_after_forward = [(t.grad_written, t.grad_masked) for t in self.tensors]
         self.plan_bwd = lib.plan_create()
         lib.plan_begin(self.plan_bwd)
         self.grad_buckets = []          # [(plan op end index, lo, hi)]: grads[lo:hi] are final once ops [.., end) ran
@@ -670,6 +702,45 @@ class Graph:
         # variables without one (highdim_angle.py:8-9) keep zero gradients and are never touched.
         self.n_launch_fwd = lib.plan_size(self.plan_fwd)
         self.n_launch_bwd = lib.plan_size(self.plan_bwd)
+        # Second recording of the reverse pass for the single-GPU step, with the optimiser of the large fc matrices fused into
+        # their filter-gradient kernels (LinearNode.backward); the plain plan above stays for run_backward() (tests read the
+        # gradients) and for the data-parallel step (the all-reduce needs them).
+        self.plan_bwd_fused = None
+        self._fused_vars = []
+        if self.fuse_fc_adam and self.lr is not None and any(isinstance(n, LinearNode) for n in self.nodes):
+            for t, (gw, gm) in zip(self.tensors, flags_after_forward):
+                t.grad_written, t.grad_masked = gw, gm
+            self._clk_main = self._clk_side = 0.0
+            self._side_rr = 0
+            plan = lib.plan_create()
+            lib.plan_begin(plan)
+            self._fusing = True
+            self._deferred = []
+            try:
+                for n in reversed(self.nodes):
+                    n.backward(self)
+                    for d in self._deferred:
+                        d[0] -= 1
+                    for d in [d for d in self._deferred if d[0] < 0]:
+                        d[1]()
+                        self._deferred.remove(d)
+                for d in self._deferred:
+                    d[1]()
+                self._deferred = []
+            finally:
+                self._fusing = False
+                lib.plan_end()
+            if self._fused_vars:
+                self.plan_bwd_fused = plan
+                self.n_launch_bwd_fused = lib.plan_size(plan)
+                lo = sorted(v.offset for v in self._fused_vars)
+                hi = [l + -(-next(v.size for v in self._fused_vars if v.offset == l) // 4) * 4 for l in lo]
+                assert len(lo) <= 8, "mv3d_adam_step_dev leaves at most 8 ranges untouched"
+                self._skip_lo = (C.c_int64 * len(lo))(*lo)
+                self._skip_hi = (C.c_int64 * len(hi))(*hi)
+            else:
+                lib.plan_destroy(plan)
+        self.upload_adam_state()
         return self
 
     def _bind_prepared_filters(self):
@@ -705,20 +776,18 @@ class Graph:
     def run_forward(self):
         self.lib.plan_run(self.plan_fwd, self._stream_ptr())
 
-    def begin_side(self, cost_side=0.0, cost_main=0.0):
-        """Tag the calls recorded until end_side() as side work (round-robin over the side classes); returns the
-        scratch pointer reserved for that class.  cost_side / cost_main: estimated microseconds of the side work
-        (a layer's filter gradient) and of the main-stream work recorded next (its data gradient): the side chain
-        does strictly more work than the main chain, so a greedy list schedule keeps the two clocks level by
-        leaving a filter gradient on the main stream whenever the side stream is more than one kernel ahead."""
+    def begin_side(self, cost_side=0.0, cost_main=0.0, cls=1):
+        """Tag the calls recorded until end_side() as side work of class `cls` (1: conv / fc filter gradients, 2: the fused fc
+        optimiser; a class maps to side stream (cls - 1) % n_side); returns the scratch pointer reserved for that class.
+        cost_side / cost_main: estimated microseconds of the side work and of the main-stream work recorded next (only
+        used by the optional list schedule MV3D_BALANCE)."""
         fork = self._clk_main
         if self.n_side == 0 or (self.balance_streams and self._clk_side > self._clk_main + cost_main):
             self._clk_main += cost_side + cost_main
             return self.ws_ptr
         self._clk_side = max(self._clk_side, fork) + cost_side
         self._clk_main += cost_main
-        k = self._side_rr % self.n_side
-        self._side_rr += 1
+        k = (cls - 1) % self.n_side
         self.lib.plan_side(k + 1)
         return self.ws_side[k].data_ptr()
 
@@ -744,19 +813,38 @@ class Graph:
             from .parallel import allreduce_sum_
             allreduce_sum_(self.grads, self.dist_group)
 
-    def _adam_range(self, lo, hi, stream):
-        off = lo * 4
-        self.lib.adam_step(hi - lo, self.params.data_ptr() + off, self.grads.data_ptr() + off, self.adam_m.data_ptr() + off,
-                           self.adam_v.data_ptr() + off, float(self.lr), self.beta1, self.beta2, self.eps,
-                           float(self.beta1_power), float(self.beta2_power), 1.0 / self.world_size, stream)
+    def upload_adam_state(self):
+        """lr, betas, epsilon, the two beta powers and the gradient scale (1 / world size) to the device Adam state."""
+        if self.adam_state is None or self.lr is None:
+            return
+        vals = np.array([self.lr, self.beta1, self.beta2, self.eps, self.beta1_power, self.beta2_power, 1.0 / self.world_size, 0.0], np.float32)
+        self.adam_state.copy_(torch.from_numpy(vals))
 
-    def _adam_advance(self):
+    def _adam_range(self, lo, hi, stream, skips=None):
+        off = lo * 4
+        n, slo, shi = (0, None, None) if skips is None else skips
+        self.lib.adam_step_dev(hi - lo, self.params.data_ptr() + off, self.grads.data_ptr() + off, self.adam_m.data_ptr() + off,
+                               self.adam_v.data_ptr() + off, self.adam_state.data_ptr(), n, slo, shi, stream)
+
+    def _adam_advance(self, stream=None):
+        """beta powers *= betas: on the device (behind every optimiser launch of this step) and in the host mirror the
+        checkpoints read"""
+        self.lib.adam_advance(self.adam_state.data_ptr(), self._stream_ptr() if stream is None else stream)
         self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
 
     def apply_adam(self):
         self._adam_range(0, self.flat_size, self._stream_ptr())
         self._adam_advance()
+
+    def run_backward_fused(self):
+        """Single-GPU reverse pass with the fc matrices' optimiser inside their filter-gradient kernels; one small launch
+        updates everything else (conv filters, biases, the angle MLP: 3 % of the parameters) once the side streams joined."""
+        sides, ns = self._side_ptrs()
+        st = self._stream_ptr()
+        self.lib.plan_run_range_multi(self.plan_bwd_fused, 0, self.n_launch_bwd_fused, st, sides, ns, 0)
+        self._adam_range(0, self.flat_size, st, (len(self._skip_lo), self._skip_lo, self._skip_hi))
+        self._adam_advance(st)
 
     def run_backward_with_adam(self):
         """Single-GPU reverse pass with the optimiser folded in: the backward plan is issued bucket by bucket
@@ -792,7 +880,7 @@ class Graph:
         main.wait_stream(self.adam_stream)
         for st in (self.side_streams or []):
             main.wait_stream(st)
-        self._adam_advance()
+        self._adam_advance(main.cuda_stream)
 
     def run_backward_overlapped(self, with_adam=False):
         """Data-parallel reverse pass: the recorded backward sequence is issued in segments; after each
@@ -826,6 +914,8 @@ class Graph:
         self.run_forward()
         if self.world_size > 1:
             self.run_backward_overlapped(with_adam=True)
+        elif self.plan_bwd_fused is not None:
+            self.run_backward_fused()
         elif self.overlap_adam and torch.device(self.device).type == 'cuda':
             self.run_backward_with_adam()
         else:
@@ -874,6 +964,7 @@ class Graph:
                 self.adam_v[v.offset:v.offset + v.size].view(v.shape).copy_(sd[k + '/Adam_1'])
         self.beta1_power = np.float32(float(sd['beta1_power']))
         self.beta2_power = np.float32(float(sd['beta2_power']))
+        self.upload_adam_state()
 
 
 # =============================================================================================== initialisers

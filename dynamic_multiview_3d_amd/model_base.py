@@ -93,6 +93,7 @@ class ModelBase(object):
     def enable_data_parallel(self, world_size, group=None):
         self.graph.world_size = int(world_size)
         self.graph.dist_group = group
+        self.graph.upload_adam_state()          # gradient scale 1 / world size for the SUM all-reduce
 
 
 def iteration_from_checkpoint_name(path):

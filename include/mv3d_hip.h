@@ -192,6 +192,25 @@ int mv3d_fill(void* dst, int64_t count, float value, void* stream);
 int mv3d_adam_step(int64_t count, void* p, const void* g, void* m, void* v, float lr, float beta1, float beta2,
                    float eps, float beta1_power, float beta2_power, float grad_scale, void* stream);
 
+/* Device-resident optimiser state, so that a RECORDED step replays with the current bias correction:
+ * state[MV3D_ADAM_LR .. MV3D_ADAM_GSCALE] floats (8 allocated).  mv3d_adam_step_dev is mv3d_adam_step with the scalars read
+ * from it, and leaves up to 8 index ranges [skip_lo, skip_hi) (multiples of 4) untouched; mv3d_adam_advance multiplies the two
+ * beta powers by their betas (tf.train.AdamOptimizer._finish, appearance_flow_model.py:77), one launch per step. */
+enum { MV3D_ADAM_LR = 0, MV3D_ADAM_BETA1 = 1, MV3D_ADAM_BETA2 = 2, MV3D_ADAM_EPS = 3, MV3D_ADAM_BETA1_POWER = 4, MV3D_ADAM_BETA2_POWER = 5,
+       MV3D_ADAM_GSCALE = 6, MV3D_ADAM_STATE_FLOATS = 8 };
+int mv3d_adam_step_dev(int64_t count, void* p, const void* g, void* m, void* v, const void* adam_state, int nskip,
+                       const int64_t* skip_lo, const int64_t* skip_hi, void* stream);
+int mv3d_adam_advance(void* adam_state, void* stream);
+/* linear_msra's filter gradient with the ApplyAdam update of that matrix fused into the epilogue (tf_utils.py:54-67 +
+ * appearance_flow_model.py:77): M, adam_m, adam_v [in,out] are updated in place from dM = x^T dy, which never goes to memory
+ * (24 instead of 32 B of HBM traffic per parameter over the two passes it replaces); db[out] (optional) receives the bias
+ * gradient as mv3d_fc_wgrad writes it.  Single-GPU steps only: the data-parallel step needs the gradient itself.  The caller
+ * orders this call behind the last reader of M (the layer's own data gradient).  _supported: 1 when the layer is one the fused
+ * kernel takes, 0 when mv3d_fc_wgrad + mv3d_adam_step_dev must be used. */
+int mv3d_fc_wgrad_adam(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* M, void* adam_m, void* adam_v,
+                       void* db, const void* adam_state, void* stream);
+int mv3d_fc_wgrad_adam_supported(int B, int in, int out, int x_ld, int dy_ld);
+
 /* ---- recorded plans: native replay of a fixed launch sequence (the step is static) ----------
  * Between mv3d_plan_begin() and mv3d_plan_end() every mv3d_* op call on this thread is RECORDED
  * (validated, not launched).  mv3d_plan_run() launches the recorded sequence on a stream in one

@@ -154,6 +154,65 @@ def test_fc_layers_at_benchmark_batch(case):
     run_fc_case(case)
 
 
+@pytest.mark.parametrize("case", [c for c in LC.FC_B64 + LC.FC_HIGHDIM if min(c[1], c[2]) >= 64], ids=LC.case_id)
+def test_fused_fc_wgrad_adam_equals_wgrad_then_adam(case):
+    """mv3d_fc_wgrad_adam (the optimiser of an fc matrix inside its filter-gradient kernel) against the two calls it replaces,
+    mv3d_fc_wgrad (held to the oracle above) followed by mv3d_adam_step_dev (held to the oracle in test_gpu_ops.py): parameter
+    and both Adam slots bit-identical after two steps with a changing bias correction; bias gradient identical."""
+    B, fin, fout, x_ld, y_ld = case
+    if not L().fc_wgrad_adam_supported(B, fin, fout, x_ld, y_ld):
+        pytest.skip("layer is not one of the fused kernel's")
+    rng = np.random.default_rng(1)
+    ws = Ws(int(L().fc_workspace_bytes(B, fin, fout)))
+    p0 = (rng.standard_normal((fin, fout)) / np.sqrt(fin)).astype(np.float32)
+    state = np.array([1e-4, 0.9, 0.999, 1e-8, 0.9, 0.999, 1.0, 0.0], np.float32)
+    st_a, st_b = dev(state), dev(state)
+    pa, ma, va = dev(p0), torch.zeros(fin, fout, device='cuda'), torch.zeros(fin, fout, device='cuda')
+    pb, mb, vb = dev(p0), torch.zeros(fin, fout, device='cuda'), torch.zeros(fin, fout, device='cuda')
+    for step in range(2):
+        xbuf, _ = _wide(rng, (B, fin), x_ld)
+        dybuf, _ = _wide(rng, (B, fout), y_ld)
+        dybuf *= np.float32(10.0 ** rng.integers(-5, 1))
+        dxb, ddy = dev(xbuf), dev(dybuf)
+        gm = torch.empty(fin, fout, device='cuda')
+        gb_a, gb_b = torch.empty(fout, device='cuda'), torch.empty(fout, device='cuda')
+        L().fc_wgrad(B, fin, fout, dxb.data_ptr(), x_ld, ddy.data_ptr(), y_ld, gm.data_ptr(), gb_a.data_ptr(), ws.ptr, ws.bytes, stream())
+        L().adam_step_dev(fin * fout, pa.data_ptr(), gm.data_ptr(), ma.data_ptr(), va.data_ptr(), st_a.data_ptr(), 0, None, None, stream())
+        L().adam_advance(st_a.data_ptr(), stream())
+        L().fc_wgrad_adam(B, fin, fout, dxb.data_ptr(), x_ld, ddy.data_ptr(), y_ld, pb.data_ptr(), mb.data_ptr(), vb.data_ptr(),
+                          gb_b.data_ptr(), st_b.data_ptr(), stream())
+        L().adam_advance(st_b.data_ptr(), stream())
+        np.testing.assert_array_equal(host(gb_a), host(gb_b))
+        np.testing.assert_array_equal(host(ma), host(mb))
+        np.testing.assert_array_equal(host(va), host(vb))
+        np.testing.assert_array_equal(host(pa), host(pb))
+    assert np.abs(host(pb) - p0).max() > 0
+    np.testing.assert_allclose(host(st_b)[4:6], [0.9 ** 3, 0.999 ** 3], rtol=1e-6)
+
+
+def test_fused_step_equals_unfused_step(monkeypatch):
+    """Graph.train_step with the fc optimiser fused (default) and with MV3D_FUSE_FC_ADAM=0 (bucketed Adam launches behind the
+    plain reverse pass): every parameter and Adam slot bit-identical after three steps."""
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    from tests.synth import appflow_feeds
+    feeds = appflow_feeds(np.random.default_rng(3), 4)
+    res = []
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('MV3D_FUSE_FC_ADAM', fuse)
+        model = AppearanceFlowModel({'batch_size': 4, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda')
+        g = model.graph
+        assert (g.plan_bwd_fused is not None) == (fuse == '1')
+        losses = [float(model.train_step(**feeds)) for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, g.params.cpu().numpy().copy(), g.adam_m.cpu().numpy().copy(), g.adam_v.cpu().numpy().copy(), float(g.beta1_power)))
+    (l1, p1, m1, v1, b1), (l0, p0, m0, v0, b0) = res
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)          # the scalar loss is accumulated with float atomics: last-bit differences run to run
+    assert b1 == b0
+    np.testing.assert_array_equal(m1, m0)
+    np.testing.assert_array_equal(v1, v0)
+    np.testing.assert_array_equal(p1, p0)
+
+
 def test_exact_fp32_rung_at_batch_64():
     """the MV3D_DISABLE=4096 twins (exact fp32 MFMA) of the two layers that carry the step, at the benchmarked batch"""
     old = L().set_diagnostics(4096)

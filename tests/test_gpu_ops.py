@@ -355,6 +355,29 @@ def test_adam_bit_exact_vs_oracle():
     np.testing.assert_allclose(host(dp), p, rtol=3e-7, atol=0)
 
 
+def test_adam_step_dev_matches_adam_step_and_skips_ranges():
+    """mv3d_adam_step_dev (scalars from the device state) = mv3d_adam_step bit for bit; skipped ranges stay untouched."""
+    n = 4096
+    p = RNG.standard_normal(n).astype(np.float32)
+    g = (RNG.standard_normal(n) * 1e-3).astype(np.float32)
+    pa, ma, va = dev(p), dev(np.zeros(n)), dev(np.zeros(n))
+    pb, mb, vb = dev(p), dev(np.zeros(n)), dev(np.zeros(n))
+    dg = dev(g)
+    state = dev(np.array([1e-4, 0.9, 0.999, 1e-8, 0.9 ** 3, 0.999 ** 3, 0.5, 0.0], np.float32))
+    L().adam_step(n, pa.data_ptr(), dg.data_ptr(), ma.data_ptr(), va.data_ptr(), 1e-4, 0.9, 0.999, 1e-8,
+                  float(np.float32(0.9 ** 3)), float(np.float32(0.999 ** 3)), 0.5, stream())
+    lo, hi = (C.c_int64 * 2)(64, 1024), (C.c_int64 * 2)(128, 2048)
+    L().adam_step_dev(n, pb.data_ptr(), dg.data_ptr(), mb.data_ptr(), vb.data_ptr(), state.data_ptr(), 2, lo, hi, stream())
+    keep = np.ones(n, bool)
+    keep[64:128] = False
+    keep[1024:2048] = False
+    np.testing.assert_array_equal(host(pb)[keep], host(pa)[keep])
+    np.testing.assert_array_equal(host(mb)[keep], host(ma)[keep])
+    np.testing.assert_array_equal(host(vb)[keep], host(va)[keep])
+    np.testing.assert_array_equal(host(pb)[~keep], p[~keep])
+    assert not host(mb)[~keep].any() and not host(vb)[~keep].any()
+
+
 def test_copy2d_group_sum_fill():
     src = RNG.standard_normal((4, 6)).astype(np.float32)
     ds = dev(src)

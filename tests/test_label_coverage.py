@@ -25,12 +25,17 @@ ELEMENTWISE = {
     'copy2d': 'tests/test_gpu_ops.py::test_copy2d_group_sum_fill',
     'group_sum': 'tests/test_gpu_ops.py::test_copy2d_group_sum_fill',
     'bconv_split_all': 'tests/test_gpu_layers.py::test_model_step_at_benchmark_batch',     # the bound-filter conversion
+    'fc_wgrad_adam_b3': 'tests/test_gpu_layers.py::test_fused_fc_wgrad_adam_equals_wgrad_then_adam',
+    'adam': 'tests/test_gpu_ops.py::test_adam_bit_exact_vs_oracle',
+    'adam_advance': 'tests/test_gpu_layers.py::test_fused_fc_wgrad_adam_equals_wgrad_then_adam',
 }
 
 
 def _plan_labels(graph):
     out = set()
-    for plan in (graph.plan_fwd, graph.plan_bwd):
+    for plan in (graph.plan_fwd, graph.plan_bwd, graph.plan_bwd_fused):
+        if plan is None:
+            continue
         out.update(o[0] for o in _lib.plan_ops(plan))
     return out
 
