@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             const int hr = pix / CC_HC, hc = pix - hr * CC_HC;
             const bool in = pc < NPIECES && pix < HPIX;
             voff[j] = ((hr * p.Wa + hc) * p.a_ld + c4 * 4) * 4;
-            hrc[j] = in ? (hr << 8 | hc) : 0x7f00;                     // row 127 + ih0 is never inside the image (Ha <= 64 + ... checked by the host)
+            hrc[j] = in ? (hr << 8 | hc) : 0x7fff00;                   // row 32767 + ih0 is never inside an image
         }
         auto issue = [&](int stage) {
             int n, oh0, ow0;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
                     const float4 v = *reinterpret_cast<const float4*>(raw + pc * 1024 + lane * 16);
                     uint2 hi, lo;
                     csplit4(v, hi, lo);
-                    if (hrc[j] != 0x7f00) {
+                    if (hrc[j] != 0x7fff00) {
                         const int off = (pc * 8 + psub) * 64 + ((((c4 >> 1) ^ ((hc >> 2) & 3))) << 4) + (c4 & 1) * 8;
                         *reinterpret_cast<uint2*>(hi_pl + off) = hi;
                         *reinterpret_cast<uint2*>(hi_pl + PL + off) = lo;
@@ -399,7 +399,7 @@ bool cconv_eligible(const IgemmParams& p, int* kw_out, bool* rev_out) {
     if (p.Hp[0] < 16 || p.Wp[0] < 16 || p.Hp[0] % 16 || p.Wp[0] % 16 || p.Cc % 32) return false;      // whole tiles only (branch-free epilogue)
     if (p.act == MV3D_ACT_TANH || p.gact == MV3D_ACT_TANH) return false;
     // buffer descriptors address the tensors with 32-bit byte offsets
-    if ((int64_t)p.N * p.Ha * p.Wa * p.a_ld * 4 >= 0x7fffffff || (int64_t)p.N * p.Hc * p.Wc * std::max(p.c_ld, p.g_ld) * 4 >= 0x7fffffff || p.Ha > 120) return false;
+    if ((int64_t)p.N * p.Ha * p.Wa * p.a_ld * 4 >= 0x7fffffff || (int64_t)p.N * p.Hc * p.Wc * std::max(p.c_ld, p.g_ld) * 4 >= 0x7fffffff || p.Ha > 16384) return false;
     if (p.Ka % 4 != 0 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15)) return false;
     int dh_min = 127, dw_min = 127;
     for (int t = 0; t < ntaps; ++t) { dh_min = std::min<int>(dh_min, p.taps[t].dh); dw_min = std::min<int>(dw_min, p.taps[t].dw); }

@@ -54,6 +54,34 @@ BASEPRED_B128 = [
     (DECONV, 128, 128, 128, 1, 32, 5, 2, 1, 32, True),    # dec_dimage1/d0
 ]
 
+# multiobject_appflow.MultiObjectAppFlow at 256 x 256, 'fully_conv', colour + depth + separate images (BASELINE config 5:
+# global batch 256 = 8 x 32; the 256 x 256 extension of multiobject_appflow.py:93-153 is SURVEY 8a note 2), batch 32 per GPU
+MULTIOBJ_256_B32 = [
+    (CONV, 32, 256, 256, 3, 32, 5, 2, 3, 32, False),      # pre_image*/e0
+    (CONV, 32, 256, 256, 1, 32, 5, 2, 1, 32, False),      # pre_dimage*/e0
+    (CONV, 32, 128, 128, 32, 32, 5, 1, 32, 32, True),     # pre_*/e0_0, dec_*/d1_0
+    (CONV, 32, 128, 128, 32, 32, 5, 2, 32, 32, True),     # pre_*/e1
+    (CONV, 32, 64, 64, 32, 32, 5, 1, 32, 32, True),       # pre_*/e1_0
+    (CONV, 32, 64, 64, 32, 64, 5, 2, 32, 256, True),      # pre_*/e2 into the 4-tower concat buffer
+    (CONV, 32, 32, 32, 256, 64, 5, 1, 256, 64, True),     # e2_0
+    (CONV, 32, 32, 32, 64, 128, 3, 2, 64, 128, True),     # e3
+    (CONV, 32, 16, 16, 128, 128, 3, 1, 128, 128, True),   # e3_0, d4_0
+    (CONV, 32, 16, 16, 128, 256, 3, 2, 128, 256, True),   # e4
+    (CONV, 32, 8, 8, 256, 256, 3, 1, 256, 320, True),     # e4_0 into the [e4_0, tiled angle code] buffer
+    (CONV, 32, 8, 8, 320, 256, 3, 1, 320, 256, True),     # e4_1
+    (CONV, 32, 8, 8, 256, 256, 3, 1, 256, 256, True),     # e4_2
+    (DECONV, 32, 16, 16, 128, 256, 3, 2, 128, 256, True), # d4
+    (DECONV, 32, 32, 32, 64, 128, 3, 2, 64, 128, True),   # d3
+    (CONV, 32, 32, 32, 64, 384, 5, 1, 64, 384, True),     # d3_0 for six decoders
+    (DECONV, 32, 64, 64, 32, 64, 5, 2, 32, 384, True),    # dec_*/d2 (its slice of d3_0)
+    (CONV, 32, 64, 64, 32, 64, 5, 1, 32, 64, True),       # dec_*/d2_0
+    (DECONV, 32, 128, 128, 32, 64, 5, 2, 32, 64, True),   # dec_*/d1
+    (DECONV, 32, 256, 256, 2, 32, 5, 2, 2, 32, True),     # flow heads
+    (DECONV, 32, 256, 256, 1, 32, 5, 2, 1, 32, True),     # depth heads
+]
+MULTIOBJ_256_CONF = {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'gen_sep_images': '', 'fully_conv': '', 'image_size': 256}
+FC_MULTIOBJ = [(32, 2, 64, 2, 64), (32, 64, 64, 64, 64)]       # the angle MLP (a0, a1 / a2)
+
 FC_B64 = [  # B, in, out, x_ld, y_ld
     (64, 4096, 4096, 4096, 4160),     # fc1 (writes into the [fc1, a2] concat buffer)
     (64, 2, 64, 2, 64),               # a0

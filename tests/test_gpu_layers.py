@@ -149,7 +149,13 @@ def test_base_prediction_layers_at_batch_128(case):
     run_conv_case(case)
 
 
-@pytest.mark.parametrize("case", LC.FC_B64 + LC.FC_HIGHDIM, ids=LC.case_id)
+@pytest.mark.parametrize("case", LC.MULTIOBJ_256_B32, ids=LC.case_id)
+def test_multiobject_256_layers_at_batch_32(case):
+    """multiobject_appflow.py:93-153 at 256 x 256 (BASELINE config 5), batch 32 per GPU."""
+    run_conv_case(case)
+
+
+@pytest.mark.parametrize("case", LC.FC_B64 + LC.FC_HIGHDIM + LC.FC_MULTIOBJ, ids=LC.case_id)
 def test_fc_layers_at_benchmark_batch(case):
     run_fc_case(case)
 

@@ -204,6 +204,45 @@ def test_multiobject_appflow(extra):
     _check_generic(model, omodels.multiobject_builder(conf), f, names)
 
 
+def test_multiobject_appflow_256x256():
+    """BASELINE config 5 (SURVEY 8a note 2: every spatial constant of multiobject_appflow.py:21-22,93-100,155 doubled, fully
+    convolutional bottleneck): all outputs, loss and every gradient vs the oracle graph at 256 x 256, batch 2."""
+    from dynamic_multiview_3d_amd.multiobject_appflow import MultiObjectAppFlow
+    from tests.synth import multiobj_feeds
+    from tests.layer_cases import MULTIOBJ_256_CONF
+    conf = dict(MULTIOBJ_256_CONF, batch_size=2, learning_rate=1e-4)
+    model = MultiObjectAppFlow(conf, load_tfrec=False, device='cuda')
+    assert model.gen_image1.shape == (2, 256, 256, 3) and model.graph.variables['e4_1/w'].shape == (3, 3, 320, 256)
+    f = multiobj_feeds(np.random.default_rng(5), 2, 256)
+    names = {a: a for a in ('gen_image1', 'gen_image1_only0', 'gen_image1_only1', 'gen_depth1', 'gen_depth1_only0',
+                            'gen_depth1_only1') if getattr(model, a) is not None}
+    assert len(names) == 6
+    _check_generic(model, omodels.multiobject_builder(conf), f, names)
+
+
+def test_multiobject_appflow_256x256_full_batch_properties():
+    """The same configuration at its full per-GPU batch (32 x 256 x 256: too large for the oracle in a test) through properties
+    that do not depend on the size: finite outputs, a loss that decreases over five Adam steps on a fixed batch, and the
+    known answer of the sampler -- with every flow head zeroed the flow decoders return the transposed
+    source image bit for bit."""
+    from dynamic_multiview_3d_amd.multiobject_appflow import MultiObjectAppFlow
+    from tests.synth import multiobj_feeds
+    from tests.layer_cases import MULTIOBJ_256_CONF
+    conf = dict(MULTIOBJ_256_CONF, batch_size=32, learning_rate=1e-4)
+    model = MultiObjectAppFlow(conf, load_tfrec=False, device='cuda')
+    g = model.graph
+    f = multiobj_feeds(np.random.default_rng(6), 32, 256)
+    losses = [float(model.train_step(**f))] + [float(model.train_step()) for _ in range(5)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    for a in ('gen_image1', 'gen_depth1', 'gen_image1_only0'):
+        assert np.isfinite(getattr(model, a).numpy()).all()
+    heads = {k: np.zeros(v.shape, np.float32) for k, v in g.variables.items() if k.endswith('/d0/w') and v.shape[2] == 2}
+    assert len(heads) == 3                                             # gen_image1, gen_image1_only0, gen_image1_only1
+    g.set_variables(heads)
+    model.forward(**f)
+    np.testing.assert_array_equal(model.gen_image1.numpy(), f['image0'].transpose(0, 2, 1, 3))
+
+
 @pytest.mark.parametrize("extra", [
     {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'gen_sep_images': '', 'masked_image_loss': '', 'fully_conv': ''},
     {'use_color': '', 'combination_image': '', 'predict_target_masks': 0.5},

@@ -151,3 +151,98 @@ def test_saver_writes_tf_names_and_state_file(tmp_path):
     assert st['model_checkpoint_path'] == p2 and st['all_model_checkpoint_paths'] == [prefix, p2]
     with pytest.raises(FileNotFoundError):
         m.saver.restore(None, str(tmp_path / 'out' / 'model-41'))
+
+
+def _v(n):
+    """protobuf / leveldb varint"""
+    out = bytearray()
+    while n >= 0x80:
+        out.append((n & 0x7F) | 0x80)
+        n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def test_multi_tensor_bundle_known_answer(tmp_path):
+    """Byte-level known answer for a bundle as tf.train.Saver (V2) lays it out -- derived here, independently of
+    tf_checkpoint.py's encoder, from the formats themselves:
+      * tensorflow/core/protobuf/tensor_bundle.proto: BundleHeaderProto{num_shards=1, endianness=LITTLE(0, omitted),
+        version{producer=1}} under the empty key; one BundleEntryProto{dtype=1, shape=2, shard_id=3 (0: omitted),
+        offset=4 (0: omitted), size=5, crc32c=6 fixed32} per tensor, keys in bytewise order (BundleWriter keeps a std::map);
+      * tensorflow/core/lib/io/table (the LevelDB table format): entries (shared, non_shared, value_len varints, key delta,
+        value) with the key prefix-compressed against its predecessor, a restart point (shared = 0) every 16 entries, the
+        restart offsets + their count as fixed32 at the end of the block, a 5-byte trailer (type 0 + masked crc32c of
+        block || type) per block, the empty meta-index block, the index block (restart interval 1) and the 48-byte footer
+        (meta-index handle, index handle, zero padding to 40 bytes, magic 0xdb4775248b80fb57 little-endian).
+    The variable set is the reference's: weights with their Adam slots and the two beta powers (train.py:70-71 saves
+    GLOBAL_VARIABLES) -- 18 tensors, so the data block has two restart points."""
+    rng = np.random.default_rng(7)
+    tensors = {'beta1_power': np.float32(0.9 ** 4), 'beta2_power': np.float32(0.999 ** 4)}
+    for layer, shape in (('e0/w', (5, 5, 3, 2)), ('e0/b', (2,)), ('fc1/Matrix', (4, 3)), ('fc1/b', (3,)), ('flow_field/w', (5, 5, 2, 1)),
+                         ('pre_image0/e0/w', (1, 1, 1, 4))):
+        tensors[layer] = rng.standard_normal(shape).astype(np.float32)
+        if layer != 'pre_image0/e0/w':
+            tensors[layer + '/Adam'] = rng.standard_normal(shape).astype(np.float32)
+            tensors[layer + '/Adam_1'] = np.abs(rng.standard_normal(shape)).astype(np.float32)
+    assert len(tensors) == 18
+    prefix = str(tmp_path / 'model20000')
+    T.write_checkpoint(prefix, tensors)
+
+    keys = sorted(tensors, key=lambda s: s.encode())
+    assert keys[:3] == ['beta1_power', 'beta2_power', 'e0/b'] and keys[3:5] == ['e0/b/Adam', 'e0/b/Adam_1']
+    # data file: the tensors' bytes back to back in key order
+    data = b''.join(np.ascontiguousarray(tensors[k]).tobytes() for k in keys)
+    assert open(prefix + '.data-00000-of-00001', 'rb').read() == data
+
+    # ---- expected index file, built from the format description
+    entries = [(b'', bytes.fromhex('0801' '1a020801'))]
+    off = 0
+    for k in keys:
+        a = np.ascontiguousarray(tensors[k])
+        shape = b''.join(b'\x12' + _v(len(b'\x08' + _v(d))) + b'\x08' + _v(d) for d in np.shape(tensors[k]))      # () for the beta powers
+        e = b'\x08\x01' + b'\x12' + _v(len(shape)) + shape                       # dtype DT_FLOAT = 1; shape (empty message for scalars)
+        if off:
+            e += b'\x20' + _v(off)
+        e += b'\x28' + _v(a.nbytes) + b'\x35' + struct.pack('<I', T.masked_crc32c(a.tobytes()))
+        entries.append((k.encode(), e))
+        off += a.nbytes
+    block, restarts, prev = bytearray(), [], b''
+    for i, (k, v) in enumerate(entries):
+        shared = 0
+        if i % 16 == 0:
+            restarts.append(len(block))
+        else:
+            while shared < min(len(k), len(prev)) and k[shared] == prev[shared]:
+                shared += 1
+        block += _v(shared) + _v(len(k) - shared) + _v(len(v)) + k[shared:] + v
+        prev = k
+    assert len(entries) == 19 and len(restarts) == 2 and restarts[0] == 0
+    block += b''.join(struct.pack('<I', r) for r in restarts) + struct.pack('<I', len(restarts))
+    data_block = bytes(block)
+
+    def trailer(b):
+        return b'\x00' + struct.pack('<I', T.masked_crc32c(b + b'\x00'))
+    meta_block = struct.pack('<II', 0, 1)
+    meta_off = len(data_block) + 5
+    index_off = meta_off + len(meta_block) + 5
+    # index block: ONE entry, key = the shortest successor of the last key (its first byte + 1), value = handle of the data block
+    last = entries[-1][0]
+    assert last == b'pre_image0/e0/w'
+    handle = _v(0) + _v(len(data_block))
+    index_block = _v(0) + _v(1) + _v(len(handle)) + b'q' + handle + struct.pack('<II', 0, 1)
+    footer = _v(meta_off) + _v(len(meta_block)) + _v(index_off) + _v(len(index_block))
+    footer += b'\x00' * (40 - len(footer)) + bytes.fromhex('57fb808b247547db')
+    expected = data_block + trailer(data_block) + meta_block + trailer(meta_block) + index_block + trailer(index_block) + footer
+    raw = open(prefix + '.index', 'rb').read()
+    assert len(raw) == len(expected)
+    assert raw == expected
+    # spot literals: 'beta2_power' shares 4 bytes with 'beta1_power'; the 17th entry restarts with shared = 0
+    assert bytes([4, 7]) + _v(len(entries[2][1])) + b'2_power' in raw
+    k16 = entries[16][0]
+    assert raw[restarts[1]:restarts[1] + 3 + len(k16)] == bytes([0, len(k16), len(entries[16][1])]) + k16
+    # and the reader returns the tensors, shapes and dtypes (scalars stay scalars)
+    back = T.read_checkpoint(prefix)
+    assert list(back) == keys
+    for k in keys:
+        np.testing.assert_array_equal(back[k], tensors[k])
+        assert back[k].shape == np.shape(tensors[k])
