@@ -152,7 +152,10 @@ def main():
     ap.add_argument('--event-every', type=int, default=8, help='steps of the timed region that carry HIP events on the conv/deconv family: every n-th')
     ap.add_argument('--dump-kernels', action='store_true', help='print the per-kernel table to stderr')
     ap.add_argument('--dump-ops', action='store_true', help='print every launch of the step in order to stderr')
-    ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument('--backend', default='rccl', help="gradient exchange: rccl = RCCL through the C ABI (mv3d_comm_*), nccl = torch.distributed's RCCL binding, "
+                                                      "gloo = CPU collectives (rehearsals on one GPU)")
+    ap.add_argument('--dp-mode', default='sharded', choices=['sharded', 'allreduce'],
+                    help="sharded: reduce-scatter -> Adam on 1/N of every bucket -> all-gather; allreduce: SUM + redundant Adam")
     ap.add_argument('--single-device', action='store_true', help='rehearsal: all ranks share GPU 0')
     args = ap.parse_args()
 
@@ -171,10 +174,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        dist.init_process_group('gloo', rank=rank, world_size=world)      # control plane: rendezvous, RCCL id, barriers, the max over ranks
 
     from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
     from dynamic_multiview_3d_amd import _lib
@@ -184,7 +184,9 @@ def main():
     g = model.graph
     model.feed(**synth_batch(np.random.default_rng(rank), args.batch))                           # resident in HBM
     if world > 1:
-        model.enable_data_parallel(world)
+        from dynamic_multiview_3d_amd import parallel
+        comm = parallel.make_comm(rank, world, args.backend)
+        model.enable_data_parallel(world, comm=comm, mode=args.dp_mode)
     lib = g.lib
 
     def sync():
@@ -313,7 +315,7 @@ def main():
     if gc_was_enabled:
         gc.enable()
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     loss = float(g.loss_buf[0])
@@ -342,6 +344,7 @@ def main():
         "config": {"workload": "appflow_offset: AppearanceFlowModel 128x128x3, batch %d per GPU, Adam lr 1e-4, "
                                "random-init weights (reference initialisers)" % args.batch,
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                   "exchange": (None if world == 1 else "%s, %s" % (type(g.comm).__name__, g.dp_mode)),
                    "precision": "conv / deconv / fc GEMMs: fp32 operands split into bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 products per "
                                 "fp32 product, fp32 accumulation (error ~1e-6 of the tensor scale; MV3D_DISABLE=4096 selects the exact "
                                 "fp32-MFMA kernels); activations, loss, resampler, Adam and all stored tensors fp32",
@@ -444,6 +447,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        if g.comm is not None:
+            g.comm.close()
         dist.destroy_process_group()
 
 

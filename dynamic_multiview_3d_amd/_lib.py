@@ -61,6 +61,12 @@ STATUS_FUNCS = {
     "mv3d_adam_step_dev": [_i64, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_i64), C.POINTER(_i64), _vp],
     "mv3d_adam_advance": [_vp, _vp],
     "mv3d_fc_wgrad_adam": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mv3d_comm_unique_id": [_vp],
+    "mv3d_comm_init": [C.POINTER(_vp), _i, _i, _vp],
+    "mv3d_comm_destroy": [_vp],
+    "mv3d_comm_allreduce_sum": [_vp, _vp, _i64, _vp],
+    "mv3d_comm_reduce_scatter_sum": [_vp, _vp, _vp, _i64, _vp],
+    "mv3d_comm_allgather": [_vp, _vp, _vp, _i64, _vp],
     "mv3d_filter_cache_bind": [_G, _i, _vp, _vp, _sz],
     "mv3d_filter_cache_commit": [_vp, _sz, _vp],
     "mv3d_filter_cache_refresh": [_vp],
@@ -92,6 +98,7 @@ OTHER_FUNCS = {
     "mv3d_plan_create": (_vp, []),
     "mv3d_plan_destroy": (None, [_vp]),
     "mv3d_plan_size": (_i, [_vp]),
+    "mv3d_comm_available": (_i, []),
     "mv3d_fc_wgrad_adam_supported": (_i, [_i, _i, _i, _i, _i]),
     "mv3d_debug_cconv_stamps": (_i, [_vp, _sz]),
 }

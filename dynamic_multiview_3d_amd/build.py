@@ -18,6 +18,7 @@ UNITS = {
     "wgrad_tile.hip": [],
     "fc.hip": [],
     "elem.hip": ["-ffp-contract=off"],
+    "comm.hip": [],                     # RCCL resolved at run time (dlsym): no link-time dependency
     "tfrecord.hip": ["-msse4.2"],       # host code only: the input thread's record reader (hardware crc32c)
 }
 COMMON = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -53,7 +54,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

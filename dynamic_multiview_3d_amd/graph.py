@@ -490,6 +490,9 @@ class Graph:
         self.beta1_power = np.float32(self.beta1)
         self.beta2_power = np.float32(self.beta2)
         self.world_size, self.dist_group = 1, None
+        self.comm = None                # parallel.TorchComm / parallel.RcclComm once data parallel is enabled
+        self.dp_mode = 'sharded'        # 'sharded': reduce-scatter -> Adam on 1/world of every bucket -> all-gather; 'allreduce': SUM + redundant Adam
+        self.comm_stream = None
         self.bucket_elems = 16 * 1024 * 1024        # 64 MB of fp32 gradients per all-reduce bucket
 
     def __enter__(self):
@@ -810,8 +813,7 @@ class Graph:
 
     def allreduce_grads(self):
         if self.world_size > 1:
-            from .parallel import allreduce_sum_
-            allreduce_sum_(self.grads, self.dist_group)
+            self.comm.allreduce_sum_(self.grads, 0, self.flat_size, self._stream_ptr())
 
     def upload_adam_state(self):
         """lr, betas, epsilon, the two beta powers and the gradient scale (1 / world size) to the device Adam state."""
@@ -883,31 +885,49 @@ class Graph:
         self._adam_advance(main.cuda_stream)
 
     def run_backward_overlapped(self, with_adam=False):
-        """Data-parallel reverse pass: the recorded backward sequence is issued in segments; after each
-        segment the gradients it completed (a contiguous suffix range of the flat buffer, >= 64 MB) are
-        SUM-all-reduced asynchronously (RCCL runs on the process group's own stream behind an event on
-        the compute stream), so the exchange of the fc gradients -- 97 % of the bytes, finished after
-        ~60 % of the backward FLOPs -- overlaps the encoder's backward kernels."""
-        import torch.distributed as dist
-        stream = self._stream_ptr()
+        """Data-parallel reverse pass.  The recorded backward sequence is issued in segments; after each segment the gradients
+        it completed -- a contiguous suffix range of the flat buffer, >= 64 MB: the fc matrices, 97 % of the bytes, are final
+        after the decoder's half of the reverse pass -- go to the communicator on its own stream while the next segment computes:
+          'sharded'    reduce-scatter(SUM) of the bucket -> TF-Adam on this rank's 1/world slice of it (grad scale 1/world) ->
+                       all-gather of the updated parameters, all on the communication stream.  The optimiser's 28 B/param are
+                       paid once per node instead of once per GPU, and the all-gather of a bucket only overwrites weights no
+                       later kernel of this step reads (a layer's data gradient precedes its bucket).
+          'allreduce'  SUM all-reduce of the bucket, then Adam on all of it on every rank (identical weights by construction).
+        Both leave bit-identical weights on every rank (tests/test_dist_cpu.py)."""
+        main = self._stream_ptr()
         sides, ns = self._side_ptrs()
-        begin, works = 0, []
+        on_gpu = torch.device(self.device).type == 'cuda'
+        if on_gpu and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+        cs = self.comm_stream.cuda_stream if on_gpu else None
+        comm, W = self.comm, self.world_size
+        begin = 0
         for end, lo, hi in self.grad_buckets:
-            self.lib.plan_run_range_multi(self.plan_bwd, begin, end, stream, sides, ns, 0)
+            self.lib.plan_run_range_multi(self.plan_bwd, begin, end, main, sides, ns, 0)      # joins the side streams
             begin = end
-            if hi > lo:
-                works.append((dist.all_reduce(self.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.dist_group, async_op=True), lo, hi))
-        if not with_adam:
-            for w, _, _ in works:
-                w.wait()                # stream-level wait: Adam is ordered behind the collectives
-            return
-        # Adam bucket by bucket: the slice whose all-reduce has finished is updated while the later (smaller, but
-        # later-started) collectives are still on the links -- the optimiser's 1.95 GB of HBM traffic hides under
-        # whatever part of the exchange the reverse pass could not cover
-        for w, lo, hi in works:
-            w.wait()
-            self._adam_range(lo, hi, self._stream_ptr())
-        self._adam_advance()
+            if hi <= lo:
+                continue
+            if on_gpu:
+                self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                ctx = torch.cuda.stream(self.comm_stream)      # a torch.distributed communicator takes the current stream
+                ctx.__enter__()
+            if self.dp_mode == 'sharded' and with_adam:
+                n = (hi - lo) // W
+                assert n * W == hi - lo and n % 4 == 0, "bucket not divisible by 4 * world"
+                comm.reduce_scatter_sum_(self.grads, lo, n, cs)
+                a = lo + comm.rank * n
+                self._adam_range(a, a + n, cs)
+                comm.allgather_(self.params, lo, n, cs)
+            else:
+                comm.allreduce_sum_(self.grads, lo, hi - lo, cs)
+                if with_adam:
+                    self._adam_range(lo, hi, cs)
+            if on_gpu:
+                ctx.__exit__(None, None, None)
+        if on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        if with_adam:
+            self._adam_advance()
 
     def train_step(self):
         """forward + loss + reverse pass + (all-reduce) + Adam; returns the device loss scalar."""

@@ -90,10 +90,17 @@ class ModelBase(object):
         return self.graph.loss_buf[0]
 
     # ---- data-parallel hook
-    def enable_data_parallel(self, world_size, group=None):
-        self.graph.world_size = int(world_size)
-        self.graph.dist_group = group
-        self.graph.upload_adam_state()          # gradient scale 1 / world size for the SUM all-reduce
+    def enable_data_parallel(self, world_size, group=None, comm=None, mode=None):
+        """comm: parallel.RcclComm (the product path: RCCL through the C ABI) or parallel.TorchComm (default: torch.distributed
+        on `group`; gloo in the CPU rehearsals).  mode: 'sharded' (default) or 'allreduce' -- Graph.run_backward_overlapped."""
+        from .parallel import TorchComm
+        g = self.graph
+        g.world_size = int(world_size)
+        g.dist_group = group
+        g.comm = comm if comm is not None else TorchComm(group)
+        if mode is not None:
+            g.dp_mode = mode
+        g.upload_adam_state()          # gradient scale 1 / world size for the SUM
 
 
 def iteration_from_checkpoint_name(path):

@@ -1,4 +1,6 @@
-"""Data-parallel plumbing: one process per GPU, torch.distributed (backend 'nccl' = RCCL over xGMI).
+"""Data-parallel plumbing: one process per GPU; the gradient exchange runs on RCCL over xGMI through the C ABI
+(include/mv3d_hip.h mv3d_comm_*: RcclComm), torch.distributed only carries the control plane (rendezvous, the 128-byte
+RCCL id, barriers) -- and the whole exchange in the CPU rehearsals (TorchComm on gloo).
 
 The reference has no distributed code: training is single process / single device.
 The train step shards naturally over the batch -- every sample is independent and the only batch
@@ -23,9 +25,35 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = 'gloo'            # control plane only: the gradient exchange has its own communicator (make_comm)
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def make_comm(rank, world, backend='rccl'):
+    """Communicator of the data-parallel step.  backend 'rccl': RCCL through the C ABI (csrc/comm.hip), the id travels over the
+    control-plane group (gloo) -- every rank must succeed, otherwise all ranks fall back together to 'nccl' = torch.distributed's
+    own RCCL binding; 'gloo': the control-plane group itself (CPU rehearsals).  torch.distributed must be initialised (gloo)."""
+    import torch.distributed as dist
+    if backend == 'rccl':
+        comm, err = None, None
+        try:
+            comm = RcclComm(rank, world)
+        except Exception as e:          # noqa: BLE001 -- any failure must be agreed on by all ranks before anyone proceeds
+            err = e
+        ok = torch.tensor([1 if comm is not None else 0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return comm
+        if comm is not None:
+            comm.close()
+        if rank == 0:
+            import sys
+            print("[mv3d] RCCL through the C ABI unavailable on some rank (%r): falling back to torch.distributed nccl" % (err,), file=sys.stderr)
+        backend = 'nccl'
+    if backend == 'nccl':
+        return TorchComm(dist.new_group(backend='nccl'))
+    return TorchComm(None)
 
 
 def bucket_views(flat, bucket_elems):
@@ -54,3 +82,77 @@ def shard_batch(global_batch, rank, world):
         raise ValueError("global batch %d not divisible by world size %d" % (global_batch, world))
     per = global_batch // world
     return rank * per, (rank + 1) * per
+
+
+# ----------------------------------------------------------------------------------------------------- communicators
+class TorchComm:
+    """The three collectives of the data-parallel step on torch.distributed (gloo on the CPU: tests and rehearsals; the
+    product path on GPUs is RcclComm).  Tensors are flat fp32 buffers; `lo`, `n` are element offsets / counts."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def allreduce_sum_(self, buf, lo, n, stream=None):
+        self.dist.all_reduce(buf[lo:lo + n], op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def reduce_scatter_sum_(self, buf, lo, n, stream=None):
+        """in place: slice `rank` of buf[lo : lo + world*n] receives the sum over ranks of that slice"""
+        w = self.world
+        tmp = buf[lo:lo + w * n].clone()                   # gloo has no reduce-scatter: sum everything, keep the own slice
+        self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM, group=self.group)
+        a = lo + self.rank * n
+        buf[a:a + n].copy_(tmp[self.rank * n:(self.rank + 1) * n])
+
+    def allgather_(self, buf, lo, n, stream=None):
+        """in place: every rank contributes slice `rank` of buf[lo : lo + world*n]"""
+        w = self.world
+        a = lo + self.rank * n
+        parts = [torch.empty(n, dtype=buf.dtype, device=buf.device) for _ in range(w)]
+        self.dist.all_gather(parts, buf[a:a + n].clone(), group=self.group)
+        for r, t in enumerate(parts):
+            buf[lo + r * n:lo + (r + 1) * n].copy_(t)
+
+    def close(self):
+        pass
+
+
+class RcclComm:
+    """RCCL behind the C ABI (csrc/comm.hip).  The 128-byte id travels from rank 0 over the control-plane process group
+    (torch.distributed, gloo); every rank then joins on its own, already selected, device."""
+
+    def __init__(self, rank, world, control_group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        self.lib = _lib.lib()
+        self.rank, self.world = rank, world
+        if not self.lib.comm_available():
+            raise _lib.Mv3dError("no RCCL in this process (librccl.so not found)")
+        ids = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            self.lib.comm_unique_id(buf)
+            ids = [buf.raw]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0, group=control_group)
+        self._id = C.create_string_buffer(ids[0], 128)
+        self._comm = C.c_void_p()
+        self.lib.comm_init(C.byref(self._comm), rank, world, self._id)
+
+    def allreduce_sum_(self, buf, lo, n, stream):
+        self.lib.comm_allreduce_sum(self._comm, buf.data_ptr() + 4 * lo, n, stream)
+
+    def reduce_scatter_sum_(self, buf, lo, n, stream):
+        base = buf.data_ptr() + 4 * lo
+        self.lib.comm_reduce_scatter_sum(self._comm, base, base + 4 * self.rank * n, n, stream)      # in place: recv = send + rank*n
+
+    def allgather_(self, buf, lo, n, stream):
+        base = buf.data_ptr() + 4 * lo
+        self.lib.comm_allgather(self._comm, base + 4 * self.rank * n, base, n, stream)
+
+    def close(self):
+        if self._comm:
+            self.lib.comm_destroy(self._comm)
+            self._comm = None

@@ -125,7 +125,8 @@ def main(argv=None):
     Model = select_model(conf)
     model = Model(conf, load_tfrec=True, build_loss=not FLAGS.visualize, device=dev)
     if world > 1:
-        model.enable_data_parallel(world)
+        comm = parallel.make_comm(rank, world, 'rccl' if torch.cuda.is_available() else 'gloo')
+        model.enable_data_parallel(world, comm=comm)
     saver = model.saver
     data_dir = conf.get('data_dir')
     if not FLAGS.synthetic and data_dir and os.path.isdir(data_dir) and os.listdir(data_dir):

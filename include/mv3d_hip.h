@@ -211,6 +211,22 @@ int mv3d_fc_wgrad_adam(int B, int in, int out, const void* x, int x_ld, const vo
                        void* db, const void* adam_state, void* stream);
 int mv3d_fc_wgrad_adam_supported(int B, int in, int out, int x_ld, int dy_ld);
 
+/* ---- data-parallel exchange: RCCL over xGMI behind the ABI (one process per GPU) -----------------------------------------
+ * The reference trains on one device (multi_view_model/train.py:21,35); the batch shards over ranks and the flat fp32 gradient
+ * buffer is summed across them.  RCCL is looked up in the process image at run time (the host program's own
+ * librccl / HIP runtime); without it every call returns MV3D_E_UNSUPPORTED.  Rank 0 creates a 128-byte id
+ * (mv3d_comm_unique_id) and hands it to the other ranks by any side channel (file, environment, TCP store); every rank then
+ * calls mv3d_comm_init on its own device.  Collectives are in place on `stream`, fp32, SUM; counts are in elements.
+ * reduce_scatter: send holds world * recv_count elements, rank r receives the sum of slice r; allgather is its inverse. */
+typedef struct mv3d_comm mv3d_comm;
+int mv3d_comm_available(void);
+int mv3d_comm_unique_id(void* id128);
+int mv3d_comm_init(mv3d_comm** out, int rank, int world, const void* id128);
+int mv3d_comm_destroy(mv3d_comm* comm);
+int mv3d_comm_allreduce_sum(mv3d_comm* comm, void* buf, int64_t count, void* stream);
+int mv3d_comm_reduce_scatter_sum(mv3d_comm* comm, const void* send, void* recv, int64_t recv_count, void* stream);
+int mv3d_comm_allgather(mv3d_comm* comm, const void* send, void* recv, int64_t send_count, void* stream);
+
 /* ---- recorded plans: native replay of a fixed launch sequence (the step is static) ----------
  * Between mv3d_plan_begin() and mv3d_plan_end() every mv3d_* op call on this thread is RECORDED
  * (validated, not launched).  mv3d_plan_run() launches the recorded sequence on a stream in one
