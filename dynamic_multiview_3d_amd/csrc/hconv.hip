@@ -536,7 +536,9 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
             if (b3 && bconv_lds_bytes(x) <= 150 * 1024 && ws && ws_bytes >= wfb && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
                 IgemmParams q = p;
                 const size_t used = (wfb + 255) & ~(size_t)255;
-                int ksplit = std::max(1, std::min(x.chunks, 512 / std::max(1, tiles * ny * zph)));
+                static int si_blocks = -1;
+                if (si_blocks < 0) { const char* e = getenv("MV3D_SI_BLOCKS"); si_blocks = e ? atoi(e) : 512; }
+                int ksplit = std::max(1, std::min(x.chunks, si_blocks / std::max(1, tiles * ny * zph)));
                 const size_t per_split = (size_t)p.N * p.Hc * p.Wc * p.Cc * sizeof(float);
                 while (ksplit > 1 && used + (size_t)ksplit * per_split > ws_bytes) --ksplit;
                 x.ksplit = ksplit;

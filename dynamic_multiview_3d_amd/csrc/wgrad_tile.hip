@@ -455,6 +455,295 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined split-bf16 filter gradient (the cconv.hip structure applied to Conv2DBackpropFilter): stride-1 5x5 / 3x3
+// layers on feature maps of at least 8 x 16 pixels, one 32 x 32 (channel x filter) tile of the filter per workgroup.
+//   * waves 4-7 ("D"): the fp32 halo of x and the tile of dy of stage s+2 travel HBM -> LDS by LDS-DMA through buffer
+//     descriptors (out-of-image lanes read zeros), the pieces of stage s+1 are split into bf16 hi / lo planes LDS -> LDS; a wave
+//     converts exactly the pieces its own DMA wrote.  The bias gradient (column sums of dy) is accumulated on the way.
+//   * waves 0-3 ("M"): each owns up to 7 taps of the filter tile, accumulators in registers over the whole slab of tiles;
+//     both operands come from the planes with the transposing read ds_read_b64_tr_b16 at compile-time offsets from ONE
+//     address register per tap (the 16-pixel step loop is unrolled), operands of the next tap in flight under the MFMAs.
+//   * one workgroup barrier per stage (= one 8 x 16-pixel tile); the per-slab partial filter leaves once, at the end.
+// LDS (5x5): 2 x (x planes 30 KiB + dy planes 16 KiB) + 46 KiB raw = 138 KiB: one workgroup per CU.
+struct CwParams {
+    const float* img; const float* feat; float* out; float* bias_out;
+    int N, H, W, C, img_ld, Ho, Wo, K, feat_ld;
+    int pt, pl, tiles_h, tiles_w, ctiles, ntiles_total, tiles_per_slab, ntaps;
+};
+
+__device__ __forceinline__ void cw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int KW>
+__global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
+    constexpr int NTAPS = KW * KW;
+    constexpr int TPW = (NTAPS + 3) / 4;                  // taps per M wave (7 / 3); the first NTAPS % 4 waves take one more than the rest
+    constexpr int HR = 7 + KW, HC = 15 + KW;              // halo of an 8 x 16 tile
+    constexpr int HPIX = HR * HC;
+    constexpr int XPL = HPIX * 64, FPL = 128 * 64;        // bytes of one x / dy plane
+    constexpr int BUF = 2 * XPL + 2 * FPL;                // hi + lo of both operands
+    constexpr int XPIECES = (HPIX + 7) / 8, NPIECES = XPIECES + 16;
+    constexpr int PPW = (NPIECES + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smc[];
+    unsigned char* const raw = smc + 2 * BUF;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = blockIdx.x % p.ctiles, kt = blockIdx.x / p.ctiles;
+    const int c0 = ct * 32, k0 = kt * 32;
+    const int slab = blockIdx.y;
+    const int tile_begin = slab * p.tiles_per_slab;
+    const int tile_end = min(tile_begin + p.tiles_per_slab, p.ntiles_total);
+    const int nstages = max(tile_end - tile_begin, 0);
+    auto origin = [&](int stage, int& n, int& oh0, int& ow0) {
+        int b = tile_begin + stage;
+        const int tw_i = b % p.tiles_w; b /= p.tiles_w;
+        const int th_i = b % p.tiles_h;
+        n = b / p.tiles_h; oh0 = th_i * 8; ow0 = tw_i * 16;
+    };
+
+    if (wave >= 4) {
+        // ---------------------------------------------------------------------------------------------- D waves
+        const int dwv = wave - 4;
+        __builtin_amdgcn_s_setprio(2);
+        const int c4 = lane & 7, psub = lane >> 3;
+        const int64_t xb = (int64_t)p.N * p.H * p.W * p.img_ld * 4, fb = (int64_t)p.N * p.Ho * p.Wo * p.feat_ld * 4;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.img), 0, (int)(xb < 0x7fffffff ? xb : 0x7fffffff), 0x00020000);
+        const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feat), 0, (int)(fb < 0x7fffffff ? fb : 0x7fffffff), 0x00020000);
+        // per-lane constants of this wave's pieces: x pieces first (halo pixels), then the dy pieces (tile pixels)
+        int voff[PPW], rc[PPW];                                       // byte offset from the stage origin; (row << 8 | column), 0x7fff00 = no pixel
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int pc = dwv + 4 * j;
+            if (pc < XPIECES) {
+                const int pix = pc * 8 + psub;
+                const int hr = pix / HC, hc = pix - hr * HC;
+                voff[j] = ((hr * p.W + hc) * p.img_ld + c4 * 4) * 4;
+                rc[j] = pix < HPIX ? (hr << 8 | hc) : 0x7fff00;
+            } else {
+                const int pq = (pc - XPIECES) * 8 + psub;
+                const int r = pq >> 4, c = pq & 15;
+                voff[j] = ((r * p.Wo + c) * p.feat_ld + c4 * 4) * 4;
+                rc[j] = pc < NPIECES ? (r << 8 | c) : 0x7fff00;
+            }
+        }
+        const bool xch_ok = c0 + c4 * 4 < p.C, fch_ok = k0 + c4 * 4 < p.K;
+        auto issue = [&](int stage) {
+            int n, oh0, ow0;
+            origin(stage, n, oh0, ow0);
+            const int ih0 = oh0 - p.pt, iw0 = ow0 - p.pl;
+            const int xso = (((n * p.H + ih0) * p.W + iw0) * p.img_ld + c0) * 4;
+            const int fso = (((n * p.Ho + oh0) * p.Wo + ow0) * p.feat_ld + k0) * 4;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const int pc = dwv + 4 * j;
+                if (pc < NPIECES) {
+                    const int r = rc[j] >> 8, c = rc[j] & 255;
+                    if (pc < XPIECES) {
+                        const bool ok = xch_ok && (unsigned)(ih0 + r) < (unsigned)p.H && (unsigned)(iw0 + c) < (unsigned)p.W;
+                        const int off = ok ? voff[j] + xso : (int)0x80000000;      // a named value: with the conditional inline hipcc (ROCm 7.2) drops the kernel's host stub
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(raw + pc * 1024), 16, off, 0, 0, 0);
+                    } else {
+                        const bool ok = fch_ok && oh0 + r < p.Ho && ow0 + c < p.Wo;
+                        const int off = ok ? voff[j] + fso : (int)0x80000000;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (__attribute__((address_space(3))) void*)(raw + pc * 1024), 16, off, 0, 0, 0);
+                    }
+                }
+            }
+        };
+        float4 bsum[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto convert = [&](int stage) {
+            unsigned char* const b = smc + (stage & 1) * BUF;
+            int fj = 0;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const int pc = dwv + 4 * j;
+                if (pc < NPIECES) {
+                    const float4 v = *reinterpret_cast<const float4*>(raw + pc * 1024 + lane * 16);
+                    uint2 hi, lo;
+                    wsplit4(v, hi, lo);
+                    if (pc < XPIECES) {
+                        if (rc[j] != 0x7fff00) {
+                            unsigned char* d = b + (pc * 8 + psub) * 64 + c4 * 8;
+                            *reinterpret_cast<uint2*>(d) = hi;
+                            *reinterpret_cast<uint2*>(d + XPL) = lo;
+                        }
+                    } else {
+                        unsigned char* d = b + 2 * XPL + ((pc - XPIECES) * 8 + psub) * 64 + c4 * 8;
+                        *reinterpret_cast<uint2*>(d) = hi;
+                        *reinterpret_cast<uint2*>(d + FPL) = lo;
+                        // bias gradient: this lane always sees filters k0 + 4 c4 .. + 3 (out-of-range lanes were loaded as zeros)
+                        if (fj < 4) { bsum[fj].x += v.x; bsum[fj].y += v.y; bsum[fj].z += v.z; bsum[fj].w += v.w; }
+                        ++fj;
+                    }
+                }
+            }
+        };
+        if (nstages > 0) {
+            issue(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            convert(0);
+            if (nstages > 1) issue(1);
+        }
+        cw_barrier();
+        for (int s = 0; s < nstages; ++s) {
+            if (s + 1 < nstages) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                convert(s + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (s + 2 < nstages) issue(s + 2);
+            }
+            cw_barrier();
+        }
+        // bias gradient of this slab: 256 lanes x 4 float4 partial sums -> 32 column sums, fixed order (buffers are free now)
+        cw_barrier();                                                      // M waves are past their last reads
+        if (p.bias_out != nullptr && ct == 0) {
+            float4* bx = reinterpret_cast<float4*>(smc);
+            float4 t = bsum[0];
+            t.x += bsum[1].x + bsum[2].x + bsum[3].x; t.y += bsum[1].y + bsum[2].y + bsum[3].y;
+            t.z += bsum[1].z + bsum[2].z + bsum[3].z; t.w += bsum[1].w + bsum[2].w + bsum[3].w;
+            bx[(tid - 256)] = t;
+        }
+        cw_barrier();
+        if (p.bias_out != nullptr && ct == 0 && tid - 256 < 32) {
+            const int kk = tid - 256;                                      // column k0 + kk: lanes with c4 == kk >> 2, component kk & 3
+            const float* bf = reinterpret_cast<const float*>(smc);
+            float t = 0.f;
+            for (int l = 0; l < 32; ++l) t += bf[((l * 8 + (kk >> 2)) * 4) + (kk & 3)];
+            if (k0 + kk < p.K) p.bias_out[(int64_t)slab * p.K + k0 + kk] = t;
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------------------------------------- M waves
+    const int li = lane & 31, lh = lane >> 5;
+    const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
+    const int lane_a = (8 * lh + q) * 64 + (16 * g16 + 4 * pp) * 2;     // row of pixel 8 lh + q of a 16-pixel step + column bytes of the transposing read
+    // taps of this wave: [tap_lo, tap_lo + tap_n)
+    constexpr int REM = NTAPS % 4, BASE = NTAPS / 4;
+    const int tap_n = BASE + (wave < REM ? 1 : 0);
+    const int tap_lo = wave * BASE + (wave < REM ? wave : REM);
+    int tapoff[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int tap = min(tap_lo + i, NTAPS - 1);
+        tapoff[i] = ((tap / KW) * HC + (tap % KW)) * 64;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    cw_barrier();                                                          // stage 0 is in buffer 0
+    for (int s = 0; s < nstages; ++s) {
+        const unsigned char* const buf = smc + (s & 1) * BUF;
+        const unsigned char* va[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) va[i] = buf + lane_a + tapoff[i];
+        const unsigned char* const vb = buf + 2 * XPL + lane_a;
+        // One flat sequence of 8 steps x TPW taps: operands of tap t + PD are issued before the MFMAs of tap t (a single MFMA
+        // wave per SIMD has nothing else to cover the LDS latency with), the dy fragments of the next step with its first tap.
+        constexpr int PD = 2;
+        constexpr int NSEQ = 8 * TPW;
+        uint2 ar[PD + 1][4];
+        uint2 br[2][4];
+        auto lda = [&](int seq, uint2 (&a)[4]) {
+            const int st = seq / TPW, i = seq % TPW;
+            const unsigned char* pa = va[i] + st * HC * 64;
+            a[0] = tr_read(pa); a[1] = tr_read(pa + 256);
+            a[2] = tr_read(pa + XPL); a[3] = tr_read(pa + XPL + 256);
+        };
+        auto ldb = [&](int st, uint2 (&b)[4]) {
+            b[0] = tr_read(vb + st * 1024); b[1] = tr_read(vb + st * 1024 + 256);
+            b[2] = tr_read(vb + FPL + st * 1024); b[3] = tr_read(vb + FPL + st * 1024 + 256);
+        };
+        ldb(0, br[0]);
+#pragma unroll
+        for (int u = 0; u < PD; ++u) lda(u, ar[u]);
+#pragma unroll
+        for (int seq = 0; seq < NSEQ; ++seq) {
+            const int st = seq / TPW, i = seq % TPW;
+            if (seq + PD < NSEQ) lda(seq + PD, ar[(seq + PD) % (PD + 1)]);
+            if (i == 0 && st + 1 < 8) ldb(st + 1, br[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint2 (&a)[4] = ar[seq % (PD + 1)];
+            const uint2 (&b)[4] = br[st & 1];
+            const wbf16x8 ah = __builtin_bit_cast(wbf16x8, make_uint4(a[0].x, a[0].y, a[1].x, a[1].y));
+            const wbf16x8 al = __builtin_bit_cast(wbf16x8, make_uint4(a[2].x, a[2].y, a[3].x, a[3].y));
+            const wbf16x8 bh = __builtin_bit_cast(wbf16x8, make_uint4(b[0].x, b[0].y, b[1].x, b[1].y));
+            const wbf16x8 bl = __builtin_bit_cast(wbf16x8, make_uint4(b[2].x, b[2].y, b[3].x, b[3].y));
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+        }
+        cw_barrier();
+    }
+    cw_barrier();                                                          // pairs with the D waves' two bias barriers
+    cw_barrier();
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        if (i >= tap_n) continue;
+        float* out = p.out + ((int64_t)slab * p.ntaps + tap_lo + i) * p.C * p.K;
+        const int k = k0 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (c < p.C && k < p.K) out[(int64_t)c * p.K + k] = acc[i][r];
+        }
+    }
+}
+
+// planning: eligible geometry -> number of slabs (0 = not eligible); every caller (workspace sizing, launch) goes through here
+static int cwgrad_plan(const mv3d_conv_geom* g, CwParams* out) {
+    if ((disabled_paths() & (2 | 4096 | 2097152)) || g->sh != 1 || g->sw != 1 || g->kh != g->kw || (g->kh != 5 && g->kh != 3)) return 0;
+    if (g->Ho < 8 || g->Wo < 16 || g->Ho % 8 || g->Wo % 16 || g->C % 32 || g->K % 32 || g->img_ld % 4 || g->feat_ld % 4) return 0;
+    if ((int64_t)g->N * g->H * g->W * g->img_ld * 4 >= 0x7fffffff || (int64_t)g->N * g->Ho * g->Wo * g->feat_ld * 4 >= 0x7fffffff) return 0;
+    CwParams p = {};
+    int ho, wo;
+    same_pad(g->H, g->kh, 1, &ho, &p.pt);
+    same_pad(g->W, g->kw, 1, &wo, &p.pl);
+    p.N = g->N; p.H = g->H; p.W = g->W; p.C = g->C; p.img_ld = g->img_ld; p.Ho = g->Ho; p.Wo = g->Wo; p.K = g->K; p.feat_ld = g->feat_ld;
+    p.tiles_h = g->Ho / 8; p.tiles_w = g->Wo / 16; p.ctiles = g->C / 32; p.ntaps = g->kh * g->kw;
+    p.ntiles_total = g->N * p.tiles_h * p.tiles_w;
+    static int min_tiles = -1;
+    if (min_tiles < 0) { const char* e = getenv("MV3D_CW_MINTILES"); min_tiles = e ? atoi(e) : 64; }
+    if (p.ntiles_total < min_tiles) return 0;
+    const int blocks_xy = p.ctiles * (g->K / 32);
+    static int wg_cus = -1;
+    if (wg_cus < 0) { const char* e = getenv("MV3D_WG_CUS"); wg_cus = e ? atoi(e) : 128; }
+    int nslab = std::max(1, wg_cus / blocks_xy);
+    if (nslab > p.ntiles_total) nslab = p.ntiles_total;
+    p.tiles_per_slab = cdiv(p.ntiles_total, nslab);
+    nslab = cdiv(p.ntiles_total, p.tiles_per_slab);
+    *out = p;
+    return nslab;
+}
+
+template <int KW>
+static int cwgrad_launch_t(const mv3d_conv_geom* g, CwParams p, int nslab, void* stream, const char* who) {
+    const double flops = 2.0 * g->N * g->Ho * g->Wo * g->kh * g->kw * (double)g->C * g->K;
+    const double bytes = 4.0 * ((double)g->N * g->H * g->W * g->C + (double)g->N * g->Ho * g->Wo * g->K + (double)g->kh * g->kw * g->C * g->K);
+    dim3 grid(p.ctiles * (g->K / 32), nslab);
+    constexpr int hpix = (7 + KW) * (15 + KW);
+    const size_t lds = 2 * (size_t)(2 * hpix * 64 + 2 * 128 * 64) + (size_t)((hpix + 7) / 8 + 16) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwgrad_kernel<KW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    return dispatch(stream, OpInfo{KW == 5 ? "cwgrad<5x5>" : "cwgrad<3x3>", flops, bytes}, [=](hipStream_t s) {
+        cwgrad_kernel<KW><<<grid, 512, lds, s>>>(p);
+        return launched(who);
+    });
+}
+
+static int cwgrad_launch(const mv3d_conv_geom* g, CwParams p, int nslab, void* stream, const char* who) {
+    return g->kw == 5 ? cwgrad_launch_t<5>(g, p, nslab, stream, who) : cwgrad_launch_t<3>(g, p, nslab, stream, who);
+}
+
 template <int TPW, int NKT>
 static int launch_wgt(const WgTileParams& p, dim3 grid, size_t lds, void* stream, const char* name, const char* who,
                       double flops, double bytes) {
@@ -556,7 +845,7 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     // one workgroup per CU in total (operands are prefetched inside the workgroup)
     const int blocks_xy = p.ctiles * kgroups;
     static int wg_cus = -1;
-    if (wg_cus < 0) { const char* e = getenv("MV3D_WG_CUS"); wg_cus = e ? atoi(e) : 256; }
+    if (wg_cus < 0) { const char* e = getenv("MV3D_WG_CUS"); wg_cus = e ? atoi(e) : 128; }      // 128: half the CUs (measured +3 % on the step over 256: fewer partial filters, room for the main stream)
     int nslab = std::max(1, wg_cus / blocks_xy);
     if (nslab > p.ntiles_total) nslab = p.ntiles_total;
     p.tiles_per_slab = cdiv(p.ntiles_total, nslab);
@@ -594,12 +883,22 @@ int wgrad_tile_launch(const mv3d_conv_geom* g, WgTileParams p, int nslab, int cf
 }
 
 int wgrad_tile_nslab(const mv3d_conv_geom* g) {
+    { CwParams cp; const int ns = cwgrad_plan(g, &cp); if (ns > 0) return ns; }
     WgTileParams p; int nslab, cfg; size_t lds;
     return wgrad_tile_plan(g, &p, &nslab, &cfg, &lds) ? nslab : 0;
 }
 
 int wgrad_tile_launch_erased(const mv3d_conv_geom* g, const void* img, const void* feat, void* out, void* bias_out, void* stream,
                              const char* who, int* nslab_out) {
+    {
+        CwParams cp;
+        const int ns = cwgrad_plan(g, &cp);
+        if (ns > 0) {
+            cp.img = (const float*)img; cp.feat = (const float*)feat; cp.out = (float*)out; cp.bias_out = (float*)bias_out;
+            *nslab_out = ns;
+            return cwgrad_launch(g, cp, ns, stream, who);
+        }
+    }
     WgTileParams p; int nslab, cfg; size_t lds;
     if (!wgrad_tile_plan(g, &p, &nslab, &cfg, &lds)) return fail(MV3D_E_INVAL, "%s: tiled wgrad not applicable", who);
     p.img = (const float*)img; p.feat = (const float*)feat; p.out = (float*)out; p.bias_out = (float*)bias_out;

@@ -18,3 +18,14 @@ cp $(find "$out/pmc_fetch" -name "*counter_collection.csv" | head -1) "$out/pmc_
 cp $(find "$out/pmc_write" -name "*counter_collection.csv" | head -1) "$out/pmc_write_size.csv"
 rm -rf "$out/trace" "$out/pmc_fetch" "$out/pmc_write"
 ls -la "$out"; head -4 "$out/timeline.txt"; cut -c1-260 "$out/bench.json"
+# SQ counters of the pipelined convolution kernels on the layer that carries the step (e0_0 / d1_0: 64 x 64 x 64 x 32 -> 32, 5x5)
+cd /tmp
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$out/pmc_sq1" -- python3 "$GRAFT_REPO_ROOT/tools/cconv_stamps.py" > /dev/null 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_IFETCH --output-format csv -d "$out/pmc_sq2" -- python3 "$GRAFT_REPO_ROOT/tools/cconv_stamps.py" > /dev/null 2>&1
+cd "$GRAFT_REPO_ROOT"
+{ echo "# rocprofv3 --pmc (two passes), tools/cconv_stamps.py: conv2d forward 64x64x64x32 -> 32, 5x5 (e0_0 / d1_0 at batch 64), mean per launch";
+  python3 tools/pmc_summary.py "$out/pmc_sq1" cconv; python3 tools/pmc_summary.py "$out/pmc_sq2" cconv; } > "$out/pmc_cconv_e0_0.txt" 2>&1
+MV3D_DBG=32 timeout -k 10 100 python3 tools/cconv_stamps.py > "$out/stamps_cconv_e0_0.txt" 2>&1
+MV3D_DBG=32 timeout -k 10 100 python3 tools/cconv_stamps.py --dgrad >> "$out/stamps_cconv_e0_0.txt" 2>&1
+rm -rf "$out/pmc_sq1" "$out/pmc_sq2"
+ls -la "$out"
