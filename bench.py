@@ -42,7 +42,7 @@ PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 
 def is_split_bf16(label):
     """Kernels that evaluate every fp32 product as three bf16 MFMA products (bconv.hip)."""
-    return label.startswith('bconv') or '_b3' in label
+    return label.startswith(('bconv', 'cconv', 'cwgrad')) or '_b3' in label
 
 
 # conv / deconv family: forward, data-gradient and filter-gradient kernels of conv2d_msra / deconv2d_msra
@@ -88,7 +88,7 @@ def _cpu_model():
     return platform.processor() or 'unknown'
 
 
-def cpu_baseline(batches=(8, 64), warmup=3, steps=10):
+def cpu_baseline(batches=(8, 64), warmup=3, steps=10, budget_s=25.0):
     """the CPU restatement of the TF-1.3 graph (oracle/torch_tape.py: torch CPU ops + autograd, fp32, TF-Adam)
     on the host cores; configs appflow_firsttry (batch 8) and appflow_offset (batch 64), 3 warm-up + 10 timed steps, median."""
     from oracle import models as omodels
@@ -109,20 +109,25 @@ def cpu_baseline(batches=(8, 64), warmup=3, steps=10):
         for _ in range(warmup):
             trainer.step(feeds)
         times = []
+        t_begin = time.perf_counter()
         for _ in range(steps):
             t0 = time.perf_counter()
             trainer.step(feeds)
             times.append(time.perf_counter() - t0)
+            if len(times) >= 3 and time.perf_counter() - t_begin > budget_s:      # bounded sample: stop early on a slow host
+                break
+        n_timed = len(times)
         times.sort()
         per_batch[b] = {"images_per_sec": round(b / times[len(times) // 2], 2), "median_step_s": round(times[len(times) // 2], 4),
-                        "min_step_s": round(times[0], 4)}
+                        "min_step_s": round(times[0], 4), "timed_steps": n_timed}
     main_b = batches[-1]
     return {"value": per_batch[main_b]["images_per_sec"], "unit": "images/sec", "cores": threads, "kind": "port",
             "cpu_model": _cpu_model(), "cpus_available": avail,
             "by_batch": {str(b): v for b, v in per_batch.items()},
             "sample": "CPU restatement of the TF-1.3 graph (oracle/torch_tape.py: torch CPU convolution / matmul kernels + autograd, "
-                      "fp32, TF-Adam; TensorFlow 1.3 itself cannot run offline), AppearanceFlowModel fwd+bwd+Adam, %d warm-up + %d timed "
-                      "steps, median; value = batch %d, batch %d beside it" % (warmup, steps, main_b, batches[0])}
+                      "fp32, TF-Adam; TensorFlow 1.3 itself cannot run offline), AppearanceFlowModel fwd+bwd+Adam, %d warm-up + up to %d timed "
+                      "steps per batch size (at least 3, stops after %.0f s), median; value = batch %d, batch %d beside it"
+                      % (warmup, steps, budget_s, main_b, batches[0])}
 
 
 def self_launch(args):

@@ -22,7 +22,7 @@ def _fp_close(got, want, tol, what):
     scale = max(abs(want[0]), 1e-30)
     assert abs(got[0] - want[0]) <= tol * scale, (what, 'norm', got[0], want[0])
     assert abs(got[1] - want[1]) <= 40 * tol * scale, (what, 'sum', got[1], want[1])       # a sum of n terms: sqrt(n) x the per-element noise
-    assert np.abs(got[2:] - want[2:]).max() <= tol * max(np.abs(want[2:]).max(), scale * 1e-3), (what, 'samples')
+    assert np.abs(got[2:] - want[2:]).max() <= 3 * tol * max(np.abs(want[2:]).max(), scale * 1e-3), (what, 'samples')      # single elements: 3 x the norm's bar
 
 
 @pytest.mark.parametrize('name', list(CASES))
