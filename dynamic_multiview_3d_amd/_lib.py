@@ -77,6 +77,7 @@ STATUS_FUNCS = {
     "mv3d_plan_run_range": [_vp, _i, _i, _vp],
     "mv3d_plan_run_range2": [_vp, _i, _i, _vp, _vp],
     "mv3d_plan_run_range_multi": [_vp, _i, _i, _vp, C.POINTER(_vp), _i, _i],
+    "mv3d_plan_run_side": [_vp, _i, _vp],
     "mv3d_plan_side": [_i],
     "mv3d_plan_profile": [_vp, _i],
     "mv3d_plan_profile_collect": [_vp],
@@ -92,6 +93,7 @@ OTHER_FUNCS = {
     "mv3d_fc_workspace_bytes": (_sz, [_i, _i, _i]),
     "mv3d_crc32c": (C.c_uint32, [_vp, _sz]),
     "mv3d_set_diagnostics": (C.c_int, [_i]),
+    "mv3d_set_wgrad_cus": (C.c_int, [_i]),
     "mv3d_tfrecord_close": (None, [_vp]),
     "mv3d_filter_prepared_bytes": (_sz, [_G, _i]),
     "mv3d_filter_cache_table_bytes": (_sz, []),

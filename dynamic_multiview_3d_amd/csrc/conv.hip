@@ -1293,7 +1293,9 @@ static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, voi
         return dispatch(stream, OpInfo{two ? "smallc_img2feat<N64>" : "smallc_img2feat<N32>", conv_flops(g), conv_bytes(g)}, [=](hipStream_t s) {
             const bool b3 = !(disabled_paths() & 4096) && q.kw * q.C <= 16 && (q.kh == 5 || q.kh == 3) && !two;
             if (b3) {
-                const int blocks = std::min(cdiv(items, 4), 2048);          // persistent walk: the filter split is per wave
+                static int sc_blocks = -1;
+                if (sc_blocks < 0) { const char* e = getenv("MV3D_SC_BLOCKS"); sc_blocks = e ? atoi(e) : 2048; }
+                const int blocks = std::min(cdiv(items, 4), sc_blocks);     // persistent walk: the filter split is per wave
                 if (q.kh == 5) smallc_b3_kernel<1, 5><<<blocks, 256, 0, s>>>(q, items);
                 else smallc_b3_kernel<1, 3><<<blocks, 256, 0, s>>>(q, items);
             } else if (two) smallc_img2feat_kernel<2><<<cdiv(items, 4), 256, 0, s>>>(q);
@@ -1382,6 +1384,7 @@ static void filtgrad_plan(const mv3d_conv_geom* g, FiltgradParams& p, int* nt_ou
 }
 
 int wgrad_tile_nslab(const mv3d_conv_geom* g);
+int set_wgrad_cus(int cus);
 
 static size_t filtgrad_ws_bytes(const mv3d_conv_geom* g) {
     {
@@ -1520,6 +1523,8 @@ int mv3d_filter_cache_bind(const mv3d_conv_geom* g, int op, const void* w, void*
     if (rc == 1) return fail(MV3D_E_UNSUPPORTED, "mv3d_filter_cache_bind: this operation does not take a prepared filter");
     return rc;
 }
+
+int mv3d_set_wgrad_cus(int cus) { return set_wgrad_cus(cus); }
 
 size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g) {
     if (!g || check_geom(g, "mv3d_conv_workspace_bytes") != MV3D_OK) return 0;

@@ -155,8 +155,10 @@ int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, vo
                 (void)hipStreamWaitEvent(s, p->join[k], 0);
             }
     };
+    const int held = (flags & MV3D_RUN_HOLD_CLASS2) ? 2 : -1;      // the caller issues that class itself (mv3d_plan_run_side)
     if (!p->profile) {
         for (int i = begin; i < end; ++i) {
+            if (p->ops[i].side == held) continue;
             int rc = p->ops[i].fn(stream_of(i));
             if (rc != MV3D_OK) return rc;
         }
@@ -171,6 +173,7 @@ int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, vo
         p->pool.push_back(e);
     }
     for (int i = begin; i < end; ++i) {
+        if (p->ops[i].side == held) continue;
         const bool sel = p->ops[i].selected;
         hipStream_t so = stream_of(i);
         if (sel) (void)hipEventRecord(p->pool[p->used + 2 * i], so);
@@ -180,6 +183,25 @@ int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, vo
     }
     join();
     if (end == n) p->used = need;
+    return MV3D_OK;
+}
+
+// The launches of side class `cls` that a run with MV3D_RUN_HOLD_CLASS2 left out, in recorded order on `stream` (the caller has
+// ordered it behind whatever they depend on).  Profiled plans: the events go into the slots of the pass that run just closed.
+int mv3d_plan_run_side(mv3d_plan* p, int cls, void* stream) {
+    if (!p) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_side: null plan");
+    if (mv3d::g_rec) return mv3d::fail(MV3D_E_INVAL, "mv3d_plan_run_side: cannot run while recording");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t n = p->ops.size();
+    const bool prof = p->profile && p->used >= 2 * n;
+    for (size_t i = 0; i < n; ++i) {
+        if (p->ops[i].side != cls) continue;
+        const bool sel = prof && p->ops[i].selected;
+        if (sel) (void)hipEventRecord(p->pool[p->used - 2 * n + 2 * i], s);
+        int rc = p->ops[i].fn(s);
+        if (sel) (void)hipEventRecord(p->pool[p->used - 2 * n + 2 * i + 1], s);
+        if (rc != MV3D_OK) return rc;
+    }
     return MV3D_OK;
 }
 

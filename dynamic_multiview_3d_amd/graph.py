@@ -153,9 +153,11 @@ class Variable:
         return self.graph.grads.data_ptr() + 4 * self.offset
 
     def value(self):
+        self.graph._settle()
         return self.graph.params[self.offset:self.offset + self.size].view(self.shape)
 
     def grad_value(self):
+        self.graph._settle()
         return self.graph.grads[self.offset:self.offset + self.size].view(self.shape)
 
 
@@ -230,8 +232,14 @@ class ConvNode(Node):
         n, h, w, c = img.shape
         return _lib.conv_geom(n, h, w, c, feat.shape[3], kh, kw, sh, sw, img.ld, feat.ld)
 
+    wg_cus = 0          # CUs of this layer's filter-gradient launch (0 = the library's default; Graph._mark_tail_wgrads)
+
     def workspace_bytes(self, g):
-        return g.lib.conv_workspace_bytes(C.byref(self.geom()))
+        old = g.lib.set_wgrad_cus(self.wg_cus)
+        try:
+            return g.lib.conv_workspace_bytes(C.byref(self.geom()))
+        finally:
+            g.lib.set_wgrad_cus(old)
 
     def forward(self, g):
         geom = self.geom()
@@ -249,11 +257,13 @@ class ConvNode(Node):
         kh, kw = self.k[0], self.k[1]
         us = 12.0 + 2.0 * geom.N * geom.Ho * geom.Wo * kh * kw * geom.C * geom.K / 120e6      # rough kernel time, microseconds
         ws_side = g.begin_side(us + 10.0, us if x.requires_grad else 0.0)
+        old_cus = g.lib.set_wgrad_cus(self.wg_cus)
         if self.transposed:
             g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, ws_side, g.ws_bytes, g.stream)
         else:
             g.lib.conv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr,
                                self.b.grad_ptr if self.b is not None else None, ws_side, g.ws_bytes, g.stream)
+        g.lib.set_wgrad_cus(old_cus)
         g.end_side()
         self.w.has_grad = True
         if self.b is not None:
@@ -298,10 +308,11 @@ class LinearNode(Node):
                 g.begin_side(60.0, 0.0, cls=2)          # its own stream: 400 MB of HBM traffic must not hold up the conv filter gradients
                 off = 4 * self.m.offset
                 g.lib.fc_wgrad_adam(B, fin, fout, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.ptr, g.adam_m.data_ptr() + off,
-                                    g.adam_v.data_ptr() + off, self.b.grad_ptr, g.adam_state.data_ptr(), g.stream)
+                                    g.adam_v.data_ptr() + off, self.b.grad_ptr, g.adam_state.data_ptr() + 32, g.stream)
                 g.end_side()
             g._deferred.append([g.fcadam_delay, emit])
             g._fused_vars.append(self.m)
+            g._fused_nodes.append(self)
             self.m.has_grad = self.b.has_grad = True
             return
         ws_side = g.begin_side(25.0, 32.0 if x.requires_grad else 0.0)
@@ -483,6 +494,15 @@ class Graph:
         self.fuse_fc_adam = os.environ.get('MV3D_FUSE_FC_ADAM', '1') != '0'      # single-GPU step: Adam of the fc matrices inside their filter-gradient kernels
         self._fusing = False
         self._fused_vars = []
+        # The fused fc optimiser (4 x 400 MB of HBM streaming) is not joined at the end of the step: it keeps running on its side
+        # stream under the NEXT step's encoder, and the forward pass waits for it in front of the first launch that touches an fc
+        # matrix or an fc layer's saved input (Graph._fwd_wait_idx).  Every other reader of the weights settles first (_settle()).
+        self.pipeline_fc = os.environ.get('MV3D_PIPELINE_FCADAM', '1') != '0'
+        self.fc_after_wgrads = os.environ.get('MV3D_FC_AFTER_WGRADS', '0') != '0'      # hold the fused fc optimiser until the conv filter gradients are done
+        self._fused_nodes = []
+        self._fwd_wait_idx = 0
+        self._fc_event = None
+        self._fc_pending = False
         self.plan_bwd_fused = None
         self.adam_state = None
         self.plan_fwd = self.plan_bwd = None
@@ -567,11 +587,16 @@ class Graph:
         self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.adam_state = torch.zeros(8, dtype=torch.float32, device=dev)      # include/mv3d_hip.h MV3D_ADAM_*
+        self.adam_state = torch.zeros(16, dtype=torch.float32, device=dev)     # two records (include/mv3d_hip.h MV3D_ADAM_*): [0:8] main stream, [8:16] the fused fc optimiser's stream
         self.loss_buf = torch.zeros(4, dtype=torch.float32, device=dev)
         self.zero_buf = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.zero_ptr = self.zero_buf.data_ptr()
         self.finalized = True       # pointers are valid from here on (workspace queries need them)
+        # The filter gradients of the first layers are the last launches of the reverse pass: the data-gradient chain has ended
+        # by then, so they spread over the whole chip instead of the half the side stream normally takes (mv3d_set_wgrad_cus).
+        ntail = int(os.environ.get('MV3D_TAIL_WGRADS', '3'))
+        for n in [n for n in self.nodes if isinstance(n, ConvNode)][:ntail]:
+            n.wg_cus = int(os.environ.get('MV3D_TAIL_WG_CUS', '256'))
         need = 0
         for n in self.nodes:
             if hasattr(n, 'workspace_bytes'):
@@ -647,7 +672,9 @@ class Graph:
         try:
             lib.filter_cache_refresh(None)      # first launch of the step: convert every conv filter once
             lib.fill(self.loss_buf.data_ptr(), 1, 0.0, self.stream)      # loss terms accumulate into loss_buf[0]
+            self._fwd_first_op = {}
             for n in self.nodes:
+                self._fwd_first_op[id(n)] = lib.plan_size(self.plan_fwd)
                 n.forward(self)
             self._emit_losses(with_grad=True)
         finally:
@@ -710,6 +737,7 @@ class Graph:
         # gradients) and for the data-parallel step (the all-reduce needs them).
         self.plan_bwd_fused = None
         self._fused_vars = []
+        self._fused_nodes = []
         if self.fuse_fc_adam and self.lr is not None and any(isinstance(n, LinearNode) for n in self.nodes):
             for t, (gw, gm) in zip(self.tensors, flags_after_forward):
                 t.grad_written, t.grad_masked = gw, gm
@@ -736,11 +764,29 @@ class Graph:
             if self._fused_vars:
                 self.plan_bwd_fused = plan
                 self.n_launch_bwd_fused = lib.plan_size(plan)
-                lo = sorted(v.offset for v in self._fused_vars)
-                hi = [l + -(-next(v.size for v in self._fused_vars if v.offset == l) // 4) * 4 for l in lo]
-                assert len(lo) <= 8, "mv3d_adam_step_dev leaves at most 8 ranges untouched"
-                self._skip_lo = (C.c_int64 * len(lo))(*lo)
-                self._skip_hi = (C.c_int64 * len(hi))(*hi)
+                # ranges of the flat buffers the main stream's optimiser launch leaves alone: the fused matrices, and their layers'
+                # biases (whose gradients the fused kernels produce: their Adam runs behind those kernels, on their stream)
+                def merged(ranges):
+                    out = []
+                    for lo, hi in sorted(ranges):
+                        if out and lo <= out[-1][1]:
+                            out[-1][1] = max(out[-1][1], hi)
+                        else:
+                            out.append([lo, hi])
+                    return out
+                pad4 = lambda v: (v.offset, v.offset + -(-v.size // 4) * 4)
+                biases = merged(pad4(n.b) for n in self._fused_nodes)
+                skips = merged([pad4(v) for v in self._fused_vars] + [tuple(b) for b in biases])
+                assert len(skips) <= 8, "mv3d_adam_step_dev leaves at most 8 ranges untouched"
+                self._skip_lo = (C.c_int64 * len(skips))(*[a for a, _ in skips])
+                self._skip_hi = (C.c_int64 * len(skips))(*[b for _, b in skips])
+                # the biases: ONE launch over [first bias, last bias end) that skips what lies between them
+                self._bias_span = (biases[0][0], biases[-1][1])
+                gaps = [(biases[i][1] - biases[0][0], biases[i + 1][0] - biases[0][0]) for i in range(len(biases) - 1)]
+                assert len(gaps) <= 8
+                self._bias_skip = (len(gaps), (C.c_int64 * max(1, len(gaps)))(*[a for a, _ in gaps] or [0]),
+                                   (C.c_int64 * max(1, len(gaps)))(*[b for _, b in gaps] or [0]))
+                self._fwd_wait_idx = self._first_fc_hazard()
             else:
                 lib.plan_destroy(plan)
         self.upload_adam_state()
@@ -776,8 +822,45 @@ class Graph:
     def _stream_ptr(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _first_fc_hazard(self):
+        """Index of the first forward launch that must not run before the previous step's fused fc optimiser finished: the
+        first node that reads one of those matrices or touches the storage of a fused layer's saved input (the deferred
+        kernels still read it).  None (no pipelining) when such an input is fed from outside the graph."""
+        roots = set()
+        for n in self._fused_nodes:
+            root = n.x._root()[0]
+            if root.external or n.x.storage.external:
+                return None
+            roots.add(id(root))
+        def tensors_of(node):
+            for val in vars(node).values():
+                for t in (val if isinstance(val, (list, tuple)) else (val,)):
+                    if isinstance(t, Tensor):
+                        yield t
+        fused = {id(n) for n in self._fused_nodes}
+        idx = self.n_launch_fwd
+        for n in self.nodes:
+            if id(n) in fused or any(id(t._root()[0]) in roots for t in tensors_of(n)):
+                idx = min(idx, self._fwd_first_op[id(n)])
+        return idx
+
+    def _settle(self):
+        """Order the current stream behind a fused fc optimiser still in flight from the last train step."""
+        if self._fc_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._fc_event)
+            self._fc_pending = False
+
+    settle = _settle        # public name: call before touching Graph.params / adam_m / adam_v / grads directly
+
     def run_forward(self):
-        self.lib.plan_run(self.plan_fwd, self._stream_ptr())
+        st = self._stream_ptr()
+        if self._fc_pending and 0 < self._fwd_wait_idx < self.n_launch_fwd:
+            self.lib.plan_run_range(self.plan_fwd, 0, self._fwd_wait_idx, st)
+            self._settle()
+            self.lib.plan_run_range(self.plan_fwd, self._fwd_wait_idx, self.n_launch_fwd, st)
+            return
+        self._settle()
+        self.lib.plan_run(self.plan_fwd, st)
 
     def begin_side(self, cost_side=0.0, cost_main=0.0, cls=1):
         """Tag the calls recorded until end_side() as side work of class `cls` (1: conv / fc filter gradients, 2: the fused fc
@@ -808,10 +891,12 @@ class Graph:
         return self._side_arr, self.n_side
 
     def run_backward(self):
+        self._settle()
         sides, ns = self._side_ptrs()
         self.lib.plan_run_range_multi(self.plan_bwd, 0, self.n_launch_bwd, self._stream_ptr(), sides, ns, 0)
 
     def allreduce_grads(self):
+        self._settle()
         if self.world_size > 1:
             self.comm.allreduce_sum_(self.grads, 0, self.flat_size, self._stream_ptr())
 
@@ -820,22 +905,27 @@ class Graph:
         if self.adam_state is None or self.lr is None:
             return
         vals = np.array([self.lr, self.beta1, self.beta2, self.eps, self.beta1_power, self.beta2_power, 1.0 / self.world_size, 0.0], np.float32)
-        self.adam_state.copy_(torch.from_numpy(vals))
+        self._settle()
+        self.adam_state.copy_(torch.from_numpy(np.concatenate([vals, vals])))
 
-    def _adam_range(self, lo, hi, stream, skips=None):
+    def _adam_range(self, lo, hi, stream, skips=None, state=None):
         off = lo * 4
         n, slo, shi = (0, None, None) if skips is None else skips
         self.lib.adam_step_dev(hi - lo, self.params.data_ptr() + off, self.grads.data_ptr() + off, self.adam_m.data_ptr() + off,
-                               self.adam_v.data_ptr() + off, self.adam_state.data_ptr(), n, slo, shi, stream)
+                               self.adam_v.data_ptr() + off, self.adam_state.data_ptr() if state is None else state, n, slo, shi, stream)
 
-    def _adam_advance(self, stream=None):
+    def _adam_advance(self, stream=None, both=True):
         """beta powers *= betas: on the device (behind every optimiser launch of this step) and in the host mirror the
         checkpoints read"""
-        self.lib.adam_advance(self.adam_state.data_ptr(), self._stream_ptr() if stream is None else stream)
+        st = self._stream_ptr() if stream is None else stream
+        self.lib.adam_advance(self.adam_state.data_ptr(), st)
+        if both:                                             # the fused fc optimiser's record (advanced on its own stream by run_backward_fused)
+            self.lib.adam_advance(self.adam_state.data_ptr() + 32, st)
         self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
 
     def apply_adam(self):
+        self._settle()
         self._adam_range(0, self.flat_size, self._stream_ptr())
         self._adam_advance()
 
@@ -844,9 +934,35 @@ class Graph:
         updates everything else (conv filters, biases, the angle MLP: 3 % of the parameters) once the side streams joined."""
         sides, ns = self._side_ptrs()
         st = self._stream_ptr()
-        self.lib.plan_run_range_multi(self.plan_bwd_fused, 0, self.n_launch_bwd_fused, st, sides, ns, 0)
+        pipelined = self.pipeline_fc and ns >= 2 and self._fwd_wait_idx is not None
+        self.lib.plan_run_range_multi(self.plan_bwd_fused, 0, self.n_launch_bwd_fused, st, sides, ns,
+                                      (1 if pipelined else 0) | (2 if pipelined and self.fc_after_wgrads else 0))
+        fc_state = self.adam_state.data_ptr() + 32
+        if pipelined and self.fc_after_wgrads:
+            # flags bit 2 made the plan hold the class-2 launches back: issue them now, behind the conv filter gradients
+            for k, q in enumerate(self.side_streams):
+                if k != 1 % ns:
+                    self.side_streams[1 % ns].wait_stream(q)
+            self.lib.plan_run_side(self.plan_bwd_fused, 2, self.side_streams[1 % ns].cuda_stream)
+        if pipelined:
+            main = torch.cuda.current_stream(self.device)
+            for k, q in enumerate(self.side_streams):
+                if k != 1 % ns:
+                    main.wait_stream(q)                      # the conv filter gradients: the launch below reads them
+            fcq = self.side_streams[1 % ns]                  # class 2: the fused fc optimiser
+            fc_stream = fcq.cuda_stream
+        else:
+            fc_stream = st
+        lo, hi = self._bias_span
+        self._adam_range(lo, hi, fc_stream, self._bias_skip, state=fc_state)
+        self.lib.adam_advance(fc_state, fc_stream)
+        if pipelined:
+            if self._fc_event is None:
+                self._fc_event = torch.cuda.Event()
+            self._fc_event.record(fcq)
+            self._fc_pending = True
         self._adam_range(0, self.flat_size, st, (len(self._skip_lo), self._skip_lo, self._skip_hi))
-        self._adam_advance(st)
+        self._adam_advance(st, both=False)
 
     def run_backward_with_adam(self):
         """Single-GPU reverse pass with the optimiser folded in: the backward plan is issued bucket by bucket
@@ -854,6 +970,7 @@ class Graph:
         final -- its filter-gradient kernels sit on the side streams -- Adam for that slice of the flat buffers
         starts on its own stream while the main stream continues with the data gradients of the layers below.
         Adam is pure HBM streaming (28 B per parameter), the convolution kernels it overlaps are MFMA / latency bound."""
+        self._settle()
         main = torch.cuda.current_stream(self.device)
         sides, ns = self._side_ptrs()
         if self.adam_stream is None:
@@ -894,6 +1011,7 @@ class Graph:
                        later kernel of this step reads (a layer's data gradient precedes its bucket).
           'allreduce'  SUM all-reduce of the bucket, then Adam on all of it on every rank (identical weights by construction).
         Both leave bit-identical weights on every rank (tests/test_dist_cpu.py)."""
+        self._settle()
         main = self._stream_ptr()
         sides, ns = self._side_ptrs()
         on_gpu = torch.device(self.device).type == 'cuda'
@@ -945,18 +1063,22 @@ class Graph:
 
     # ---------------------------------------------------------------- variables I/O
     def get_variables(self):
+        self._settle()
         return OrderedDict((k, v.value().detach().cpu().numpy().copy()) for k, v in self.variables.items())
 
     def set_variables(self, values):
+        self._settle()
         for k, a in values.items():
             self.variables[k].value().copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)).reshape(self.variables[k].shape))
 
     def get_gradients(self):
+        self._settle()
         return OrderedDict((k, v.grad_value().detach().cpu().numpy().copy()) for k, v in self.variables.items() if v.has_grad)
 
     def state_dict(self):
         """TF-Saver-style names: <var>, <var>/Adam, <var>/Adam_1, beta1_power, beta2_power
         (train.py:70-71 saves GLOBAL_VARIABLES)."""
+        self._settle()
         sd = OrderedDict()
         for k, v in self.variables.items():
             sd[k] = v.value().detach().cpu().clone()
@@ -968,6 +1090,7 @@ class Graph:
         return sd
 
     def load_state_dict(self, sd):
+        self._settle()
         missing = [k for k in self.variables if k not in sd]
         slots = {'beta1_power', 'beta2_power'}
         unexpected = [k for k in sd if k not in slots and k not in self.variables and

@@ -68,6 +68,10 @@ const char* mv3d_last_error(void);
 /* Diagnostics: replace the mask of disabled dispatch rungs (environment MV3D_DISABLE at load; bits in DESIGN.md 4.5);
  * returns the previous mask.  Results never change beyond rounding; 4096 selects the exact fp32-MFMA kernels. */
 int mv3d_set_diagnostics(int mask);
+/* Tuning: the number of CUs the following conv / deconv filter-gradient calls (and their workspace queries) spread their
+ * partial-filter slabs over; 0 restores the default (MV3D_WG_CUS, 128 = half the chip: those launches normally share it with
+ * the data-gradient chain).  Returns the previous value.  Results never change beyond summation order. */
+int mv3d_set_wgrad_cus(int cus);
 
 /* ---- input side (host): the reference's TFRecord shards, multi_view_model/utils/read_tf_records.py:46-85 -----------------
  * mv3d_tfrecord_read copies feature k of up to max_records records into dst[k] + (first + i) * sizes[k] (host memory, e.g. a
@@ -252,7 +256,9 @@ int mv3d_plan_side(int side);                  /* 0 = main, 1..MV3D_MAX_SIDE = s
 int mv3d_plan_run_range2(mv3d_plan* p, int begin, int end, void* stream, void* side_stream);
 /* side class k runs on side_streams[(k-1) % nside]; classes on different streams must not share scratch either */
 #define MV3D_RUN_NO_JOIN 1      /* the caller orders `stream` behind the side streams itself */
+#define MV3D_RUN_HOLD_CLASS2 2  /* leave side class 2 out: the caller issues it with mv3d_plan_run_side once ITS dependencies are met */
 int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, void* const* side_streams, int nside, int flags);
+int mv3d_plan_run_side(mv3d_plan* p, int cls, void* stream);
 /* Per-launch timing for the roofline report: with profiling enabled, mv3d_plan_run brackets every
  * recorded launch with hipEventRecord on the launch stream (no host synchronisation);
  * mv3d_plan_profile_collect() synchronises once and folds all runs into per-op totals.

@@ -156,7 +156,8 @@ class _CpuLib:
         ops.adam_step(g.params.numpy()[sl], grad, g.adam_m.numpy()[sl], g.adam_v.numpy()[sl], st[4], st[5], float(st[0]))
 
     def adam_advance(self, state, stream):
-        st = self.g.adam_state.numpy()
+        rec = (state - self.g.adam_state.data_ptr()) // 4          # 0: the main record, 8: the fused fc optimiser's copy
+        st = self.g.adam_state.numpy()[rec:rec + 8]
         st[4] *= st[1]
         st[5] *= st[2]
 

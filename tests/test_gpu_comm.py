@@ -51,6 +51,7 @@ def test_data_parallel_schedule_world_one_equals_single_gpu_step(mode, monkeypat
             else:
                 g.train_step()
         torch.cuda.synchronize()
+        g.settle()
         res.append((g.params.cpu().numpy().copy(), g.adam_m.cpu().numpy().copy(), g.adam_v.cpu().numpy().copy(), float(g.adam_state[4])))
         if dp:
             comm.close()

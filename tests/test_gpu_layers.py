@@ -210,6 +210,7 @@ def test_fused_step_equals_unfused_step(monkeypatch):
         assert (g.plan_bwd_fused is not None) == (fuse == '1')
         losses = [float(model.train_step(**feeds)) for _ in range(3)]
         torch.cuda.synchronize()
+        g.settle()
         res.append((losses, g.params.cpu().numpy().copy(), g.adam_m.cpu().numpy().copy(), g.adam_v.cpu().numpy().copy(), float(g.beta1_power)))
     (l1, p1, m1, v1, b1), (l0, p0, m0, v0, b0) = res
     np.testing.assert_allclose(l1, l0, rtol=2e-6)          # the scalar loss is accumulated with float atomics: last-bit differences run to run
@@ -217,6 +218,33 @@ def test_fused_step_equals_unfused_step(monkeypatch):
     np.testing.assert_array_equal(m1, m0)
     np.testing.assert_array_equal(v1, v0)
     np.testing.assert_array_equal(p1, p0)
+
+
+def test_pipelined_fc_optimiser_equals_joined_step(monkeypatch):
+    """The fused fc optimiser of step N runs under the encoder of step N+1 (Graph.pipeline_fc): at the benchmarked batch, four
+    steps with fresh feeds leave every parameter and Adam slot bit-identical to the schedule that joins all streams at the end
+    of each step (MV3D_PIPELINE_FCADAM=0) -- a missed dependency (a weight read early, a saved input overwritten) would show."""
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    from tests.synth import appflow_feeds
+    rng = np.random.default_rng(5)
+    feeds = [appflow_feeds(rng, 64) for _ in range(2)]
+    res = []
+    for pipe in ('1', '0'):
+        monkeypatch.setenv('MV3D_PIPELINE_FCADAM', pipe)
+        model = AppearanceFlowModel({'batch_size': 64, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda')
+        g = model.graph
+        assert g.pipeline_fc == (pipe == '1') and g.plan_bwd_fused is not None
+        assert 0 < g._fwd_wait_idx < g.n_launch_fwd
+        for step in range(4):
+            model.feed(**feeds[step % 2])
+            g.train_step()
+            assert g._fc_pending == (pipe == '1')
+        torch.cuda.synchronize()
+        res.append((g.params.cpu().numpy().copy(), g.adam_m.cpu().numpy().copy(), g.adam_v.cpu().numpy().copy(),
+                    g.adam_state.cpu().numpy().copy()))
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[0][3][:8], res[0][3][8:])          # both device Adam records advanced alike
 
 
 def test_exact_fp32_rung_at_batch_64():
