@@ -593,8 +593,8 @@ class Graph:
         self.zero_ptr = self.zero_buf.data_ptr()
         self.finalized = True       # pointers are valid from here on (workspace queries need them)
         # The filter gradients of the first layers are the last launches of the reverse pass: the data-gradient chain has ended
-        # by then, so they spread over the whole chip instead of the half the side stream normally takes (mv3d_set_wgrad_cus).
-        ntail = int(os.environ.get('MV3D_TAIL_WGRADS', '3'))
+        # by then, so they could spread over the whole chip instead of the half the side stream normally takes (mv3d_set_wgrad_cus).
+        ntail = int(os.environ.get('MV3D_TAIL_WGRADS', '0'))      # measured: no gain at B = 64 (+-0.1 %), so off
         for n in [n for n in self.nodes if isinstance(n, ConvNode)][:ntail]:
             n.wg_cus = int(os.environ.get('MV3D_TAIL_WG_CUS', '256'))
         need = 0
