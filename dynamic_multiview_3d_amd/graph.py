@@ -498,11 +498,15 @@ class Graph:
         # stream under the NEXT step's encoder, and the forward pass waits for it in front of the first launch that touches an fc
         # matrix or an fc layer's saved input (Graph._fwd_wait_idx).  Every other reader of the weights settles first (_settle()).
         self.pipeline_fc = os.environ.get('MV3D_PIPELINE_FCADAM', '1') != '0'
+        # data parallel, sharded optimiser: all-gathers of buckets first read at forward launch >= pipeline_dp_min_idx are deferred
+        self.pipeline_dp = os.environ.get('MV3D_PIPELINE_DP', '1') != '0'
+        self.pipeline_dp_min_idx = 8
         self.fc_after_wgrads = os.environ.get('MV3D_FC_AFTER_WGRADS', '0') != '0'      # hold the fused fc optimiser until the conv filter gradients are done
         self._fused_nodes = []
         self._fwd_wait_idx = 0
         self._fc_event = None
         self._fc_pending = False
+        self._pending_idx = 0           # forward launch index the pending event is waited for in front of
         self.plan_bwd_fused = None
         self.adam_state = None
         self.plan_fwd = self.plan_bwd = None
@@ -702,7 +706,16 @@ class Graph:
                 while suffix > 0 and order[suffix - 1].name in done:
                     suffix -= 1
                 lo = order[suffix].offset if suffix < len(order) else self.flat_size
-                if cut_hi - lo >= self.bucket_elems:
+                # also cut where the reverse pass moves from convolutions to an fc layer: conv filters are read by the first
+                # launch of the next step (filter conversion), fc matrices much later -- their buckets' all-gathers can run
+                # under the next step's encoder (run_backward_overlapped), a mixed bucket could not
+                boundary = False
+                if isinstance(n, ConvNode) and cut_hi > lo:
+                    for prev in reversed(self.nodes[:self.nodes.index(n)]):      # the next node of the reverse pass that owns parameters
+                        if any(isinstance(v, Variable) for v in vars(prev).values()):
+                            boundary = isinstance(prev, LinearNode)
+                            break
+                if cut_hi - lo >= self.bucket_elems or boundary:
                     self.grad_buckets.append((lib.plan_size(self.plan_bwd), lo, cut_hi))
                     cut_hi = lo
         finally:
@@ -732,6 +745,7 @@ class Graph:
         # variables without one (highdim_angle.py:8-9) keep zero gradients and are never touched.
         self.n_launch_fwd = lib.plan_size(self.plan_fwd)
         self.n_launch_bwd = lib.plan_size(self.plan_bwd)
+        self._bucket_first_use = [self._first_param_use(lo, hi) for _, lo, hi in self.grad_buckets]
         # Second recording of the reverse pass for the single-GPU step, with the optimiser of the large fc matrices fused into
         # their filter-gradient kernels (LinearNode.backward); the plain plan above stays for run_backward() (tests read the
         # gradients) and for the data-parallel step (the all-reduce needs them).
@@ -822,6 +836,16 @@ class Graph:
     def _stream_ptr(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _first_param_use(self, lo, hi):
+        """Index of the first forward launch that reads a parameter of the flat range [lo, hi): a conv filter is read by launch 0
+        (the conversion of all filters, mv3d_filter_cache_refresh), everything else by its layer's first launch."""
+        first = self.n_launch_fwd
+        for n in self.nodes:
+            for name, val in vars(n).items():
+                if isinstance(val, Variable) and val.offset is not None and lo <= val.offset < hi:
+                    first = min(first, 0 if (isinstance(n, ConvNode) and name == 'w') else self._fwd_first_op[id(n)])
+        return first
+
     def _first_fc_hazard(self):
         """Index of the first forward launch that must not run before the previous step's fused fc optimiser finished: the
         first node that reads one of those matrices or touches the storage of a fused layer's saved input (the deferred
@@ -854,10 +878,10 @@ class Graph:
 
     def run_forward(self):
         st = self._stream_ptr()
-        if self._fc_pending and 0 < self._fwd_wait_idx < self.n_launch_fwd:
-            self.lib.plan_run_range(self.plan_fwd, 0, self._fwd_wait_idx, st)
+        if self._fc_pending and 0 < self._pending_idx < self.n_launch_fwd:
+            self.lib.plan_run_range(self.plan_fwd, 0, self._pending_idx, st)
             self._settle()
-            self.lib.plan_run_range(self.plan_fwd, self._fwd_wait_idx, self.n_launch_fwd, st)
+            self.lib.plan_run_range(self.plan_fwd, self._pending_idx, self.n_launch_fwd, st)
             return
         self._settle()
         self.lib.plan_run(self.plan_fwd, st)
@@ -961,6 +985,7 @@ class Graph:
                 self._fc_event = torch.cuda.Event()
             self._fc_event.record(fcq)
             self._fc_pending = True
+            self._pending_idx = self._fwd_wait_idx
         self._adam_range(0, self.flat_size, st, (len(self._skip_lo), self._skip_lo, self._skip_hi))
         self._adam_advance(st, both=False)
 
@@ -1020,6 +1045,7 @@ class Graph:
         cs = self.comm_stream.cuda_stream if on_gpu else None
         comm, W = self.comm, self.world_size
         begin = 0
+        late = []                       # [(first forward launch that reads the bucket, lo, slice length)]
         for end, lo, hi in self.grad_buckets:
             self.lib.plan_run_range_multi(self.plan_bwd, begin, end, main, sides, ns, 0)      # joins the side streams
             begin = end
@@ -1035,7 +1061,13 @@ class Graph:
                 comm.reduce_scatter_sum_(self.grads, lo, n, cs)
                 a = lo + comm.rank * n
                 self._adam_range(a, a + n, cs)
-                comm.allgather_(self.params, lo, n, cs)
+                # the updated slices of a bucket whose parameters the next forward pass reads late (the fc matrices: 97 % of the
+                # bytes) are gathered AFTER every bucket has been reduced and, on the GPU, under the next step's encoder
+                use = self._bucket_first_use[self.grad_buckets.index((end, lo, hi))]
+                if self.pipeline_dp and use >= self.pipeline_dp_min_idx:
+                    late.append((use, lo, n))
+                else:
+                    comm.allgather_(self.params, lo, n, cs)
             else:
                 comm.allreduce_sum_(self.grads, lo, hi - lo, cs)
                 if with_adam:
@@ -1043,7 +1075,21 @@ class Graph:
             if on_gpu:
                 ctx.__exit__(None, None, None)
         if on_gpu:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)      # every reduce-scatter, Adam slice and early all-gather
+        if late:
+            late.sort()
+            if on_gpu:
+                ctx = torch.cuda.stream(self.comm_stream)
+                ctx.__enter__()
+            for _, lo, n in late:
+                comm.allgather_(self.params, lo, n, cs)
+            if on_gpu:
+                ctx.__exit__(None, None, None)
+                if self._fc_event is None:
+                    self._fc_event = torch.cuda.Event()
+                self._fc_event.record(self.comm_stream)
+                self._fc_pending = True
+                self._pending_idx = late[0][0]
         if with_adam:
             self._adam_advance()
 

@@ -121,7 +121,27 @@ def test_overlapped_bucket_allreduce_two_ranks():
         assert buckets[0][2] == flat and buckets[-1][1] == 0
         assert all(a[1] == b[2] for a, b in zip(buckets, buckets[1:]))          # contiguous, descending
         full = [b for b in buckets if b[2] > b[1]]          # an empty bucket marks the end of the fc layers (Adam gate)
-        assert len(full) >= 4 and all((hi - lo) * 4 >= 60e6 for _, lo, hi in full[:-1])
+        # the decoder's conv filters (first) and the encoder's (last) are small buckets of their own -- the next step's first
+        # launch reads them --, the fc matrices in between travel in >= 60 MB buckets
+        assert len(full) >= 5 and all((hi - lo) * 4 >= 60e6 for _, lo, hi in full[1:-1])
+        assert (full[0][2] - full[0][1]) * 4 < 8e6
+
+
+def test_late_allgather_set_is_the_fc_buckets():
+    """The sharded data-parallel step gathers a bucket's updated slices late (under the next step's encoder) only when no early
+    forward launch reads it: conv filters are read by launch 0 (filter conversion), so both conv buckets stay early; the four fc
+    buckets are first read in forward order fc1 < a3 < a4 < a5, all behind the encoder."""
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    m = AppearanceFlowModel({'batch_size': 2, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cpu')
+    g = m.graph
+    full = [(b, u) for b, u in zip(g.grad_buckets, g._bucket_first_use) if b[2] > b[1]]
+    assert full[0][1] == 0 and full[-1][1] == 0
+    late = [u for _, u in full[1:-1]]
+    assert len(late) == 4 and all(u >= g.pipeline_dp_min_idx for u in late)
+    assert late == sorted(late, reverse=True)          # buckets come in reverse-pass order, uses in forward order
+    names = {v.name: v for v in g.variables.values()}
+    fc1 = next(b for b, _ in full if b[1] <= names['fc1/Matrix'].offset < b[2])
+    assert g._first_param_use(fc1[1], fc1[2]) == min(late)
 
 
 def test_shard_batch():

@@ -60,3 +60,122 @@ def test_data_parallel_schedule_world_one_equals_single_gpu_step(mode, monkeypat
     np.testing.assert_array_equal(m1, m0)
     np.testing.assert_array_equal(v1, v0)
     np.testing.assert_array_equal(p1, p0)
+
+
+def _two_gpu_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from dynamic_multiview_3d_amd.lowdim_angle import AppFlowLowDimAngle
+    from tests.synth import appflow_feeds
+    torch.cuda.set_device(rank)                            # before any other GPU call of this process
+    parallel.init_from_env('gloo')
+    comm = parallel.make_comm(rank, world, 'rccl')
+    feeds = appflow_feeds(np.random.default_rng(3), 4 * world)
+    shard = {k: v[4 * rank:4 * (rank + 1)] for k, v in feeds.items()}
+    m = AppFlowLowDimAngle({'batch_size': 4, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda:%d' % rank, seed=11)
+    m.enable_data_parallel(world, comm=comm, mode='sharded')
+    m.feed(**shard)
+    for _ in range(2):
+        m.graph.train_step()
+    torch.cuda.synchronize()
+    q.put((rank, type(comm).__name__, m.graph.params.cpu().numpy().copy()))
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device: tools/rccl_two_ranks_one_gpu.py)")
+def test_two_gpus_data_parallel_equals_one_process_on_the_whole_batch():
+    """two ranks on two GPUs, two sharded-optimiser train steps on batch shards; rank 0 == rank 1 bitwise, and both
+    equal (to summation-order rounding) a single process that trains on the concatenated batch -- grad_scale 1 / world, the ordering
+    between the filter-gradient side streams and the communication stream, and the all-gather of the updated weights, on hardware.
+    Skipped on the one-GPU test boxes; the world-2 arithmetic of the same schedule runs on gloo in tests/test_dist_cpu.py."""
+    import socket
+    import torch.multiprocessing as mp
+    from dynamic_multiview_3d_amd.lowdim_angle import AppFlowLowDimAngle
+    from tests.synth import appflow_feeds
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        rank, kind, params = q.get(timeout=600)
+        got[rank] = params
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(got[0], got[1])
+    feeds = appflow_feeds(np.random.default_rng(3), 8)
+    m = AppFlowLowDimAngle({'batch_size': 8, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda', seed=11)
+    m.feed(**feeds)
+    for _ in range(2):
+        m.graph.train_step()
+    torch.cuda.synchronize()
+    m.graph.settle()
+    ref = m.graph.params.cpu().numpy()
+    # two Adam steps move a weight by at most 2 lr; gradients that differ in the last bits (different summation order of the
+    # batch) move it by a tiny fraction of that
+    assert np.abs(got[0] - ref).max() <= 0.05 * 2e-4
+
+
+def _one_gpu_gloo_worker(rank, world, port, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from dynamic_multiview_3d_amd.lowdim_angle import AppFlowLowDimAngle
+    from tests.synth import appflow_feeds
+    try:
+        torch.cuda.set_device(0)
+        parallel.init_from_env('gloo')
+        out = {}
+        for mode in ('allreduce', 'sharded'):
+            comm = parallel.make_comm(rank, world, 'gloo')
+            m = AppFlowLowDimAngle({'batch_size': 4, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda', seed=11)
+            g = m.graph
+            m.enable_data_parallel(world, comm=comm, mode=mode)
+            rng = np.random.default_rng(100 + rank)
+            late_seen = False
+            for _ in range(3):
+                m.feed(**appflow_feeds(rng, 4))
+                g.train_step()
+                late_seen = late_seen or g._fc_pending
+            torch.cuda.synchronize()
+            g.settle()
+            out[mode] = (g.params.cpu().numpy().copy(), late_seen)
+        q.put((rank, None, out))
+        dist.destroy_process_group()
+    except Exception as e:          # noqa: BLE001 -- reported to the parent, which fails the test with it
+        import traceback
+        q.put((rank, traceback.format_exc()[-1500:], None))
+
+
+def test_two_ranks_on_one_gpu_late_allgather_equals_allreduce():
+    """Two ranks share the test box's one GPU and exchange through gloo (RCCL refuses two ranks per device): the sharded step
+    with the fc buckets' all-gathers deferred under the next step's encoder -- real kernels, real streams, a world size at which
+    a rank only ever computes HALF of every updated bucket -- leaves the weights of the all-reduce schedule, bit for bit, on both
+    ranks after three steps with fresh per-rank batches."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_one_gpu_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, err, out = q.get(timeout=900)
+        assert err is None, err
+        res[rank] = out
+    for p in procs:
+        p.join(120)
+    for r in (0, 1):
+        assert res[r]['sharded'][1], "the late all-gather never happened"
+        assert not res[r]['allreduce'][1]
+        np.testing.assert_array_equal(res[r]['sharded'][0], res[r]['allreduce'][0])
+    np.testing.assert_array_equal(res[0]['sharded'][0], res[1]['sharded'][0])
