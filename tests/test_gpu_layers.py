@@ -257,6 +257,17 @@ def test_exact_fp32_rung_at_batch_64():
         L().set_diagnostics(old)
 
 
+def test_round1_kernels_at_batch_64():
+    """diagnostics 1048576 | 2097152: the kernels the round-2 ones replaced (bconvu for cconv, wgrad_b3 for cwgrad) stay fallback
+    rungs and stay correct at the benchmarked shapes"""
+    old = L().set_diagnostics(1048576 | 2097152)
+    try:
+        run_conv_case(LC.APPFLOW_B64[1])
+        run_conv_case(LC.APPFLOW_B64[13])
+    finally:
+        L().set_diagnostics(old)
+
+
 def test_model_step_at_benchmark_batch():
     """Whole AppearanceFlowModel at batch 64 (BASELINE config 2, what bench.py times): forward outputs, loss and all 47
     gradients against the oracle graph on the same inputs and weights -- the product's own plans (prepared-filter cache,

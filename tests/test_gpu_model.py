@@ -423,3 +423,10 @@ def test_fused_head_equals_the_three_launch_head(monkeypatch):
         assert _rel(model.gen.numpy(), out['gen']) < 1e-5
     finally:
         _lib.lib().set_diagnostics(old)
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke_runs():
+    """the driver's round-end check (`__graft_entry__.smoke()`) stays green with the rest of the suite"""
+    import __graft_entry__
+    __graft_entry__.smoke()
