@@ -910,7 +910,9 @@ class Graph:
         if self.n_side == 0 or torch.device(self.device).type != 'cuda':
             return None, 0
         if self.side_streams is None:
-            self.side_streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_side)]
+            # MV3D_SIDE_PRIORITY: comma-separated stream priorities of the side streams (0 = default, -1 = high); measured: no gain
+            prio = [int(x) for x in os.environ.get('MV3D_SIDE_PRIORITY', '').split(',') if x.strip()]
+            self.side_streams = [torch.cuda.Stream(device=self.device, priority=(prio[k] if k < len(prio) else 0)) for k in range(self.n_side)]
             self._side_arr = (C.c_void_p * self.n_side)(*[st.cuda_stream for st in self.side_streams])
         return self._side_arr, self.n_side
 
