@@ -353,9 +353,11 @@ def main():
                    "precision": "conv / deconv / fc GEMMs: fp32 operands split into bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 products per "
                                 "fp32 product, fp32 accumulation (error ~1e-6 of the tensor scale; MV3D_DISABLE=4096 selects the exact "
                                 "fp32-MFMA kernels); activations, loss, resampler, Adam and all stored tensors fp32",
-                   "launches_per_step": g.n_launch_fwd + lib.plan_size(bwd_plan) + 2,
+                   # recorded forward + reverse launches, then: fused step = Adam of the fc biases + its record's advance, the remaining
+                   # Adam launch + advance (4); otherwise one Adam launch per bucket + 2 advances (data parallel: + the collectives)
+                   "launches_per_step": g.n_launch_fwd + lib.plan_size(bwd_plan) + (4 if bwd_plan is not g.plan_bwd else len([b for b in g.grad_buckets if b[2] > b[1]]) + 2),
                    "optimiser": ("Adam of the four large fc matrices (97 % of the parameters) fused into their filter-gradient kernels "
-                                 "(mv3d_fc_wgrad_adam), one launch for the rest") if bwd_plan is not g.plan_bwd else "bucketed Adam launches"},
+                                 "(mv3d_fc_wgrad_adam) and left running under the next step's encoder, one launch for the rest") if bwd_plan is not g.plan_bwd else "bucketed Adam launches"},
         "loss": round(loss, 6),
         "step_ms": {"mean": round(ms_per_step, 4), "median": round(step_ms[len(step_ms) // 2], 4), "min": round(step_ms[0], 4),
                     "max": round(step_ms[-1], 4),

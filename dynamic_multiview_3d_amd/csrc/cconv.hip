@@ -68,13 +68,14 @@ __device__ __forceinline__ void cbarrier() { asm volatile("s_waitcnt lgkmcnt(0)\
 #endif
 constexpr int CC_HC = 20;             // halo pitch in pixels (15 + kw rounded up to a multiple of 4)
 
-template <int KW, bool REV, bool HAS_G, int U, int D>
+template <int KW, bool REV, bool HAS_G, int U, int D, int MT>
 __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const HconvExtra x, const uint4* __restrict__ Wf, int ntiles) {
     constexpr int NTAPS = KW * KW;
     static_assert(NTAPS % U == 0, "ring slots must line up across stages");
-    constexpr int MT = 2;
+    static_assert(MT == 1 || MT == 2, "tile height 8 or 16: one or two 32-pixel groups (two tile rows each) per multiplying wave");
+    constexpr int TH = 8 * MT;
     static_assert(D >= 1 && D < U, "look-ahead distance of the filter ring, in taps");
-    constexpr int HR = 15 + KW;                           // halo rows
+    constexpr int HR = TH - 1 + KW;                       // halo rows
     constexpr int HPIX = HR * CC_HC;
     constexpr int PL = HPIX * 64;                         // bytes of one bf16 plane
     constexpr int NPIECES = (HPIX + 7) / 8;               // 1 KiB pieces of the raw fp32 halo (8 pixels x 128 B)
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
         int bq = (int)blockIdx.x + (stage / chunks) * (int)gridDim.x;
         const int tw_i = bq % x.tiles_w; bq /= x.tiles_w;
         const int th_i = bq % x.tiles_h;
-        n = bq / x.tiles_h; oh0 = th_i * 16; ow0 = tw_i * 16;
+        n = bq / x.tiles_h; oh0 = th_i * TH; ow0 = tw_i * 16;
     };
 
     if (wave >= 4) {
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
 
     // -------------------------------------------------------------------------------------------------- M waves
     const int li = lane & 31, lh = lane >> 5;
-    const int tc = li & 15, tr0 = wave * 4 + (li >> 4);              // pixel group m covers tile rows tr0 + 2m
+    const int tc = li & 15, tr0 = wave * 2 * MT + (li >> 4);         // pixel group m covers tile rows tr0 + 2m
     // A-operand address registers: one per (filter column, k-step); everything else is a compile-time offset
     int vq[KW][2];
 #pragma unroll
@@ -228,8 +229,8 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
     const float g1 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.gleak) : 0.5f;
     const float g2 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.gleak) : 0.5f;
     const bool g_relu = p.gact == MV3D_ACT_RELU;
-    const int out_lane = ((wave * 4 * p.Wc + 4 * lh) * p.c_ld + col) * 4;                  // bytes
-    const int ref_lane = HAS_G ? ((wave * 4 * p.Wc + 4 * lh) * p.g_ld + col) * 4 : 0;
+    const int out_lane = ((wave * 2 * MT * p.Wc + 4 * lh) * p.c_ld + col) * 4;             // bytes
+    const int ref_lane = HAS_G ? ((wave * 2 * MT * p.Wc + 4 * lh) * p.g_ld + col) * 4 : 0;
     const int64_t o_bytes = (int64_t)p.N * p.Hc * p.Wc * p.c_ld * 4, r_bytes = (int64_t)p.N * p.Hc * p.Wc * p.g_ld * 4;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.Out, 0, (int)(o_bytes < 0x7fffffff ? o_bytes : 0x7fffffff), 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_G ? p.gref : p.Out), 0,
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
     };
     // store schedule of the tap loop: group g leaves at tap ts(g); its saved-output loads are issued D taps earlier, in front
     // of that tap's filter look-ahead loads, so the in-order vmcnt wait that covers the filter ring also covers them
-    auto ts_of = [](int g8) { return D + (g8 * (NTAPS - D)) / 8; };
+    constexpr int NG = 4 * MT;                                         // store groups per tile and wave
+    auto ts_of = [](int g8) { return D + (g8 * (NTAPS - D)) / NG; };
 
 #pragma unroll
     for (int u = 0; u < D; ++u) load_b(ring[u], u, 0);
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
 #endif
             if constexpr (PEND) {
 #pragma unroll
-                for (int g8 = 0; g8 < 8; ++g8)
+                for (int g8 = 0; g8 < NG; ++g8)
                     if (t == ts_of(g8) - D) pre_group(g8);
             }
             {   // look-ahead tap: this chunk, or the first taps of the next stage's chunk
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             }
             __builtin_amdgcn_sched_barrier(0);                         // keep the look-ahead load here (hipcc sinks it to its first use)
             const BSet& f = ring[t % U];
-#ifdef CC_EXP_ILV
+#if defined(CC_EXP_ILV)
+            static_assert(MT == 2, "experiment only");
             // the two pixel groups' accumulator chains interleaved: consecutive MFMAs never depend on each other
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk) {
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
                 if constexpr (PEND) {
                     if (sk == 0) {
 #pragma unroll
-                        for (int g8 = 0; g8 < 8; ++g8)
+                        for (int g8 = 0; g8 < NG; ++g8)
                             if (t == ts_of(g8)) fin_group(g8);
                     }
                 }
@@ -354,9 +357,9 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
                     if (t + 1 < NTAPS) read_a(t + 1 < NTAPS ? t + 1 : t, m, sk);
 #endif
                     if constexpr (PEND) {
-                        if (sk == 0 && m == 1) {
+                        if (sk == 0 && m == MT - 1) {
 #pragma unroll
-                            for (int g8 = 0; g8 < 8; ++g8)
+                            for (int g8 = 0; g8 < NG; ++g8)
                                 if (t == ts_of(g8)) fin_group(g8);
                         }
                     }
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
     }
     if (pending) {
 #pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) { pre_group(g8); fin_group(g8); }
+        for (int g8 = 0; g8 < NG; ++g8) { pre_group(g8); fin_group(g8); }
     }
 }
 
@@ -396,7 +399,7 @@ bool cconv_eligible(const IgemmParams& p, int* kw_out, bool* rev_out) {
     const int ntaps = p.tap_begin[1];
     const int kw = ntaps == 25 ? 5 : (ntaps == 9 ? 3 : 0);
     if (!kw) return false;
-    if (p.Hp[0] < 16 || p.Wp[0] < 16 || p.Hp[0] % 16 || p.Wp[0] % 16 || p.Cc % 32) return false;      // whole tiles only (branch-free epilogue)
+    if (p.Hp[0] < 16 || p.Wp[0] < 16 || p.Hp[0] % 16 || p.Wp[0] % 16 || p.Cc % 32) return false;      // whole tiles only (branch-free epilogue); 16 | Hp covers the 8-row tiles too
     if (p.act == MV3D_ACT_TANH || p.gact == MV3D_ACT_TANH) return false;
     // buffer descriptors address the tensors with 32-bit byte offsets
     if ((int64_t)p.N * p.Ha * p.Wa * p.a_ld * 4 >= 0x7fffffff || (int64_t)p.N * p.Hc * p.Wc * std::max(p.c_ld, p.g_ld) * 4 >= 0x7fffffff || p.Ha > 16384) return false;
@@ -415,21 +418,21 @@ bool cconv_eligible(const IgemmParams& p, int* kw_out, bool* rev_out) {
     return true;
 }
 
-template <int KW, bool REV, bool HAS_G>
+template <int KW, bool REV, bool HAS_G, int MT>
 static int launch_cconv_t(const IgemmParams& p, const HconvExtra& x, dim3 grid, const uint4* wf, int ntiles, void* stream,
                           const char* who, double flops, double bytes) {
     constexpr int U = KW == 5 ? 5 : 3;
     constexpr int LA = KW == 5 ? CC_LA5 : 2;             // taps of look-ahead of the filter ring (16 registers each)
-    constexpr int HPIX = (15 + KW) * CC_HC;
+    constexpr int HPIX = (8 * MT - 1 + KW) * CC_HC;
     const size_t lds = (size_t)4 * HPIX * 64 + (size_t)((HPIX + 7) / 8) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cconv_kernel<KW, REV, HAS_G, U, LA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cconv_kernel<KW, REV, HAS_G, U, LA, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const char* name = intern_label("cconv<%s,256px,N32%s>", KW == 5 ? "5x5" : "3x3", HAS_G ? ",gmask" : "");
+    const char* name = intern_label("cconv<%s,%dpx,N32%s>", KW == 5 ? "5x5" : "3x3", 128 * MT, HAS_G ? ",gmask" : "");
     return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
-        cconv_kernel<KW, REV, HAS_G, U, LA><<<grid, 512, lds, s>>>(p, x, wf, ntiles);
+        cconv_kernel<KW, REV, HAS_G, U, LA, MT><<<grid, 512, lds, s>>>(p, x, wf, ntiles);
         return launched(who);
     });
 }
@@ -443,7 +446,11 @@ int launch_cconv(const IgemmParams& p, const HconvExtra& x, const void* wf, int 
     const int ny = cdiv(p.Cc, 32);
     dim3 grid(std::min(xp.n_tiles, std::max(1, 256 / ny)), ny, 1);
     const uint4* w4 = reinterpret_cast<const uint4*>(wf);
-#define MV3D_CC(KW_, REV_, G_) launch_cconv_t<KW_, REV_, G_>(p, xp, grid, w4, ntiles, stream, who, flops, bytes)
+    // x.TH = 16: 16 x 16 tiles (two pixel groups per multiplying wave); 8: 8 x 16 tiles, for layers with fewer than two large
+    // tiles per CU (twice the workgroups, half the halo to stage before the first MFMA)
+    if (x.TH != 16 && x.TH != 8) return fail(MV3D_E_INVAL, "%s: pipelined conv tile height %d", who, x.TH);
+#define MV3D_CC(KW_, REV_, G_) (x.TH == 16 ? launch_cconv_t<KW_, REV_, G_, 2>(p, xp, grid, w4, ntiles, stream, who, flops, bytes) \
+                                           : launch_cconv_t<KW_, REV_, G_, 1>(p, xp, grid, w4, ntiles, stream, who, flops, bytes))
     const bool g = p.gact != MV3D_ACT_NONE;
     if (kw == 5) return rev ? (g ? MV3D_CC(5, true, true) : MV3D_CC(5, true, false)) : (g ? MV3D_CC(5, false, true) : MV3D_CC(5, false, false));
     return rev ? (g ? MV3D_CC(3, true, true) : MV3D_CC(3, true, false)) : (g ? MV3D_CC(3, false, true) : MV3D_CC(3, false, false));

@@ -603,10 +603,13 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
             const int ctiles = p.N * cdiv(Hp, 16) * cdiv(Wp, 16);
             if (nph == 1 && !(disabled_paths() & 1048576) && cconv_eligible(p, &ckw, &crev) && ctiles * cdiv(p.Cc, 32) >= cc_min) {
                 // pipelined kernel (cconv.hip): 16 x 16 tiles x 32 filters, one persistent workgroup per CU
-                bx.TH = 16; bx.TW = 16; bx.tw_shift = 4; bx.img_shift = 8;
-                bx.tiles_h = cdiv(Hp, 16); bx.tiles_w = cdiv(Wp, 16);
-                bx.HR = 15 + ckw; bx.HC = 20; bx.G = 1; bx.HRi = bx.HR; bx.ksplit = 1;
-                MT = 2; NT = 1; WAVES = 8; name = "cconv";
+                static int th8_below = -1;       // fewer 16 x 16 workgroup tasks than this: 8 x 16 tiles (MV3D_CC_TH8_BELOW, 0 = never)
+                if (th8_below < 0) { const char* e = getenv("MV3D_CC_TH8_BELOW"); th8_below = e ? atoi(e) : 512; }
+                const int th = ctiles * cdiv(p.Cc, 32) < th8_below ? 8 : 16;
+                bx.TH = th; bx.TW = 16; bx.tw_shift = 4; bx.img_shift = 8;
+                bx.tiles_h = cdiv(Hp, th); bx.tiles_w = cdiv(Wp, 16);
+                bx.HR = th - 1 + ckw; bx.HC = 20; bx.G = 1; bx.HRi = bx.HR; bx.ksplit = 1;
+                MT = th / 8; NT = 1; WAVES = 8; name = "cconv";
             } else if (nph == 1) {
                 struct Cand { int pix, MT, NT, WAVES; const char* name; };
                 const int n2 = p.Cc > 32 ? 2 : 1;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Times one conv layer through the C ABI and prints the in-kernel stamps of the pipelined kernel (cconv.hip, MV3D_DBG=32).
 
-    MV3D_DBG=32 python tools/cconv_stamps.py [n h w c k ksz] [--dgrad]
+    MV3D_DBG=32 python tools/cconv_stamps.py [n h w c k ksz] [--dgrad | --wgrad]
+(--wgrad: the filter gradient of the same layer, cwgrad_kernel: for the SQ counter passes; it writes no stamps)
 """
 import ctypes as C
 import os
@@ -16,6 +17,7 @@ from dynamic_multiview_3d_amd import _lib
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 n, h, w, c, k, ksz = [int(a) for a in args] if args else (64, 64, 64, 32, 32, 5)
 dgrad = '--dgrad' in sys.argv
+wgrad = '--wgrad' in sys.argv
 L = _lib.lib()
 g = _lib.conv_geom(n, h, w, c, k, ksz, ksz, 1, 1)
 wsb = int(L.conv_workspace_bytes(C.byref(g)))
@@ -28,8 +30,14 @@ ref = torch.randn(n, h, w, c, device='cuda')
 st = torch.cuda.current_stream().cuda_stream
 
 
+dw = torch.empty(ksz, ksz, c, k, device='cuda')
+db = torch.empty(k, device='cuda')
+
+
 def call():
-    if dgrad:
+    if wgrad:
+        L.conv2d_wgrad(C.byref(g), x.data_ptr(), y.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), wsb, st)
+    elif dgrad:
         epi = _lib.epilogue(None, 0, 0.2, _lib.ACT_LRELU, 0.2, ref.data_ptr(), c)
         L.conv2d_dgrad(C.byref(g), y.data_ptr(), wt.data_ptr(), x.data_ptr(), C.byref(epi), ws.data_ptr(), wsb, st)
     else:
@@ -49,8 +57,8 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 fl = 2.0 * n * h * w * ksz * ksz * c * k
-print("%s %dx%dx%dx%d->%d %dx%d: %.1f us per call (incl. the per-call filter split), %.1f TF/s" % ('dgrad' if dgrad else 'fwd', n, h, w, c, k, ksz, ksz, ms * 1e3, fl / ms / 1e9))
-if int(os.environ.get('MV3D_DBG', '0')) & 32:
+print("%s %dx%dx%dx%d->%d %dx%d: %.1f us per call (incl. the per-call filter split), %.1f TF/s" % ('wgrad' if wgrad else 'dgrad' if dgrad else 'fwd', n, h, w, c, k, ksz, ksz, ms * 1e3, fl / ms / 1e9))
+if int(os.environ.get('MV3D_DBG', '0')) & 32 and not wgrad:
     NS = 64
     buf = np.zeros(256 * 8 * NS, np.uint64)
     L.dll.mv3d_debug_cconv_stamps.argtypes = [C.c_void_p, C.c_size_t]
