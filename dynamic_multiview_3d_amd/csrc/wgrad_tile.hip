@@ -701,10 +701,11 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
 // share it with the data-gradient chain), or what mv3d_set_wgrad_cus() asked for -- the train step raises it to the whole
 // chip for the last filter gradients of the reverse pass, which run when the data-gradient chain has ended.
 static int g_wg_cus_override = 0;
-static int wgrad_cus() {
-    static int wg_cus = -1;
+static int wgrad_cus(int kh = 5) {
+    static int wg_cus = -1, wg_cus3 = -1;
     if (wg_cus < 0) { const char* e = getenv("MV3D_WG_CUS"); wg_cus = e ? atoi(e) : 128; }
-    return g_wg_cus_override > 0 ? g_wg_cus_override : wg_cus;
+    if (wg_cus3 < 0) { const char* e = getenv("MV3D_WG_CUS_3X3"); wg_cus3 = e ? atoi(e) : wg_cus; }      // the 3 x 3 layers (8 x 8 / 4 x 4 maps): latency-bound
+    return g_wg_cus_override > 0 ? g_wg_cus_override : (kh == 3 ? wg_cus3 : wg_cus);
 }
 int set_wgrad_cus(int cus) { const int old = g_wg_cus_override; g_wg_cus_override = cus > 0 ? cus : 0; return old; }
 
@@ -723,7 +724,7 @@ static int cwgrad_plan(const mv3d_conv_geom* g, CwParams* out) {
     if (min_tiles < 0) { const char* e = getenv("MV3D_CW_MINTILES"); min_tiles = e ? atoi(e) : 64; }
     if (p.ntiles_total < min_tiles) return 0;
     const int blocks_xy = p.ctiles * (g->K / 32);
-    int nslab = std::max(1, wgrad_cus() / blocks_xy);
+    int nslab = std::max(1, wgrad_cus(g->kh) / blocks_xy);
     if (nslab > p.ntiles_total) nslab = p.ntiles_total;
     p.tiles_per_slab = cdiv(p.ntiles_total, nslab);
     nslab = cdiv(p.ntiles_total, p.tiles_per_slab);
@@ -853,7 +854,7 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     p.ntiles_total = cdiv(g->N, p.G) * p.tiles_h * p.tiles_w;
     // one workgroup per CU in total (operands are prefetched inside the workgroup)
     const int blocks_xy = p.ctiles * kgroups;
-    int nslab = std::max(1, wgrad_cus() / blocks_xy);      // default 128: half the CUs (measured +3 % on the step over 256: fewer partial filters, room for the main stream)
+    int nslab = std::max(1, wgrad_cus(g->kh) / blocks_xy);      // default 128: half the CUs (measured +3 % on the step over 256: fewer partial filters, room for the main stream)
     if (nslab > p.ntiles_total) nslab = p.ntiles_total;
     p.tiles_per_slab = cdiv(p.ntiles_total, nslab);
     nslab = cdiv(p.ntiles_total, p.tiles_per_slab);
