@@ -585,6 +585,92 @@ __global__ __launch_bounds__(256) void smallc_b3_kernel(const SmallCParams p, in
     }
 }
 
+// The same arithmetic with the address arithmetic taken out (round 2; ablations of smallc_b3_kernel on the 128 x 128 x 3 -> 32
+// layer at batch 64: 48 us, 37 without the input loads, 33 without the stores, 20 with neither -- each of the 56 memory
+// instructions of an item carried its own 64-bit address computation, clamp and select).  Here the input and the output are
+// addressed through buffer descriptors: one per-lane offset register, the row / pixel part in a scalar register, the element
+// part in the instruction's immediate; image rows above / below the image come back as zeros from the descriptor's bounds check
+// (a scalar select of the row offset), columns left / right of it are masked with one v_cndmask per element from eight per-item
+// predicates; the four waves of a workgroup split the filter rows once between them (LDS) instead of once each.
+// Requires Wo % 32 == 0, K == 32, power-of-two Wo / 32 and Ho (shifts instead of divisions), tensors below 2 GiB.
+template <int KH>
+__global__ __launch_bounds__(256) void smallc_b3s_kernel(const SmallCParams p, int nitems, int wt_shift, int ho_shift) {
+    __shared__ __attribute__((aligned(16))) uint4 fsh[KH][2][64];          // [filter row][hi, lo][lane]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int Cf = p.kw * p.C;                         // <= 16
+    for (int pr = wave; pr < KH; pr += 4) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = 8 * lh + j;
+            v[j] = e < Cf ? p.Wt[((int64_t)pr * Cf + e) * p.K + li] : 0.f;
+        }
+        cbf16x8 h, l;
+        csplit8(v, h, l);
+        fsh[pr][0][lane] = __builtin_bit_cast(uint4, h);
+        fsh[pr][1][lane] = __builtin_bit_cast(uint4, l);
+    }
+    __syncthreads();
+    cbf16x8 bh[KH], bl[KH];
+#pragma unroll
+    for (int pr = 0; pr < KH; ++pr) {
+        bh[pr] = __builtin_bit_cast(cbf16x8, fsh[pr][0][lane]);
+        bl[pr] = __builtin_bit_cast(cbf16x8, fsh[pr][1][lane]);
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)((int64_t)p.N * p.H * p.W * p.C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((int64_t)p.N * p.Ho * p.Wo * p.y_ld * 4), 0x00020000);
+    const float bias = p.ep.bias ? p.ep.bias[li] : 0.f;
+    const int out_lane = (4 * lh * p.y_ld + li) * 4;                       // bytes: accumulator row 4 lh (+ r & 3 + 8 (r >> 2)), column li
+    const int row_bytes = p.W * p.C * 4;
+    int qj[8];                                                             // input column of fragment element j, relative to iw0
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qj[j] = (8 * lh + j) / p.C;
+    // (a two-register-set prefetch of the next item's rows was measured slower at every grid size: 28.7 - 38 us against 24.8)
+    for (int item = blockIdx.x * 4 + wave; item < nitems; item += gridDim.x * 4) {
+        const int wt = item & ((1 << wt_shift) - 1);
+        const int rowi = item >> wt_shift;                                 // n * Ho + ho
+        const int ho = rowi & ((1 << ho_shift) - 1), n = rowi >> ho_shift;
+        const int iw0 = (wt * 32 + li) * p.sw - p.pl;
+        const int xlane = (iw0 * p.C + 8 * lh) * 4;                        // bytes from the start of the input row (may be negative)
+        bool okj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) okj[j] = (unsigned)(iw0 + qj[j]) < (unsigned)p.W;
+        float a[KH][8];
+#pragma unroll
+        for (int pr = 0; pr < KH; ++pr) {
+            const int ih = ho * p.sh + pr - p.pt;                          // wave-uniform
+            const int so = (unsigned)ih < (unsigned)p.H ? (n * p.H + ih) * row_bytes : (int)0x80000000;
+            // a row outside the image: every lane's offset lands beyond num_records (lane offsets are far below 2^30) -> zeros
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                a[pr][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, xlane + 4 * j, so, 0));
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < KH; ++pr) {
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = okj[j] ? a[pr][j] : 0.f;
+            cbf16x8 ah, al;
+            csplit8(m, ah, al);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pr], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pr], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pr], acc, 0, 0, 0);
+        }
+        const int pix0 = rowi * p.Wo + wt * 32;                            // wave-uniform: first pixel of the item
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int pq = pix0 + (q & 3) + 8 * (q >> 2);                  // + 4 lh in the lane part
+            float v = act_apply(acc[q] + bias, p.ep.act, p.ep.leak);
+            if (p.ep.gact != MV3D_ACT_NONE) v *= act_grad_from_out(p.ep.gref[(int64_t)(pq + 4 * lh) * p.ep.g_ld + li], p.ep.gact, p.ep.gleak);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, out_lane, pq * p.y_ld * 4, 0);
+        }
+    }
+}
+
 // feat2img with a thin image side (C <= 4: flow field, rgb / depth / mask heads): one thread per
 // output pixel on the VALU, the phase's filter taps staged once per block in LDS.  These layers are
 // HBM/L2-bound (AI ~ 40 flop/B): padding 2 channels to a 32-wide MFMA tile would multiply the work by 16.
@@ -1296,7 +1382,17 @@ static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, voi
                 static int sc_blocks = -1;
                 if (sc_blocks < 0) { const char* e = getenv("MV3D_SC_BLOCKS"); sc_blocks = e ? atoi(e) : 2048; }
                 const int blocks = std::min(cdiv(items, 4), sc_blocks);     // persistent walk: the filter split is per wave
-                if (q.kh == 5) smallc_b3_kernel<1, 5><<<blocks, 256, 0, s>>>(q, items);
+                auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+                // (forward only: with a gradient mask the saved-output loads keep their 64-bit addresses and the old kernel is faster, 26.9 vs 30.2 us)
+                const bool lean = !(disabled_paths() & 8388608) && q.ep.gact == MV3D_ACT_NONE && q.Wo % 32 == 0 && q.K == 32 && pow2(q.wtiles) && pow2(q.Ho) &&
+                                  (int64_t)q.N * q.H * q.W * q.C * 4 < 0x40000000 && (int64_t)q.N * q.Ho * q.Wo * q.y_ld * 4 < 0x7fffffff;
+                if (lean) {
+                    int ws_ = 0, hs_ = 0;
+                    while ((1 << ws_) < q.wtiles) ++ws_;
+                    while ((1 << hs_) < q.Ho) ++hs_;
+                    if (q.kh == 5) smallc_b3s_kernel<5><<<blocks, 256, 0, s>>>(q, items, ws_, hs_);
+                    else smallc_b3s_kernel<3><<<blocks, 256, 0, s>>>(q, items, ws_, hs_);
+                } else if (q.kh == 5) smallc_b3_kernel<1, 5><<<blocks, 256, 0, s>>>(q, items);
                 else smallc_b3_kernel<1, 3><<<blocks, 256, 0, s>>>(q, items);
             } else if (two) smallc_img2feat_kernel<2><<<cdiv(items, 4), 256, 0, s>>>(q);
             else smallc_img2feat_kernel<1><<<cdiv(items, 4), 256, 0, s>>>(q);
