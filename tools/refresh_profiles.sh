@@ -28,9 +28,11 @@ cd "$GRAFT_REPO_ROOT"
 MV3D_DBG=32 timeout -k 10 100 python3 tools/cconv_stamps.py > "$out/stamps_cconv_e0_0.txt" 2>&1
 MV3D_DBG=32 timeout -k 10 100 python3 tools/cconv_stamps.py --dgrad >> "$out/stamps_cconv_e0_0.txt" 2>&1
 rm -rf "$out/pmc_sq1" "$out/pmc_sq2"
-# the same counters for the pipelined filter gradient of that layer (cwgrad_kernel, 128 CUs)
+# the same counters for the pipelined filter gradient of that layer (cwgrad_kernel, 128 CUs); its time from an unprofiled run
+cd "$GRAFT_REPO_ROOT"
+timeout -k 10 100 python3 tools/cconv_stamps.py --wgrad > "$out/cwgrad_time.txt" 2>&1
 cd /tmp
-timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$out/pmc_sq3" -- python3 "$GRAFT_REPO_ROOT/tools/cconv_stamps.py" --wgrad > "$out/cwgrad_time.txt" 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$out/pmc_sq3" -- python3 "$GRAFT_REPO_ROOT/tools/cconv_stamps.py" --wgrad > /dev/null 2>&1
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_IFETCH --output-format csv -d "$out/pmc_sq4" -- python3 "$GRAFT_REPO_ROOT/tools/cconv_stamps.py" --wgrad > /dev/null 2>&1
 cd "$GRAFT_REPO_ROOT"
 { echo "# rocprofv3 --pmc (two passes), tools/cconv_stamps.py --wgrad: conv2d filter gradient 64x64x64x32 -> 32, 5x5 (e0_0 / d1_0 at batch 64), mean per launch";
