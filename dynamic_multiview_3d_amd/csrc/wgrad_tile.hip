@@ -621,14 +621,17 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
     const int li = lane & 31, lh = lane >> 5;
     const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3;
     const int lane_a = (8 * lh + q) * 64 + (16 * g16 + 4 * pp) * 2;     // row of pixel 8 lh + q of a 16-pixel step + column bytes of the transposing read
-    // taps of this wave: [tap_lo, tap_lo + tap_n)
+    // taps of this wave: BASE whole ones, [tap_lo, tap_lo + BASE), and a quarter of the last tap (25 = 4 x 6 + 1, 9 = 4 x 2 + 1):
+    // slot BASE of every wave accumulates tap NTAPS - 1 over the wave's own two of the eight pixel steps of a tile; the four
+    // partial sums are added through LDS once, at the end.  (One wave taking the odd tap whole made it the stage's critical path:
+    // 7 taps against 6.25, and the other three multiplied a duplicate to keep the unrolled sequence uniform.)
     constexpr int REM = NTAPS % 4, BASE = NTAPS / 4;
-    const int tap_n = BASE + (wave < REM ? 1 : 0);
-    const int tap_lo = wave * BASE + (wave < REM ? wave : REM);
+    static_assert(REM == 1 && TPW == BASE + 1, "tap split written for 4 * BASE + 1 taps");
+    const int tap_lo = wave * BASE;
     int tapoff[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int tap = min(tap_lo + i, NTAPS - 1);
+        const int tap = i < BASE ? tap_lo + i : NTAPS - 1;
         tapoff[i] = ((tap / KW) * HC + (tap % KW)) * 64;
     }
     f32x16 acc[TPW];
@@ -660,15 +663,18 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
             b[0] = tr_read(vb + st * 1024); b[1] = tr_read(vb + st * 1024 + 256);
             b[2] = tr_read(vb + FPL + st * 1024); b[3] = tr_read(vb + FPL + st * 1024 + 256);
         };
+        // slot BASE is live only in this wave's two steps (wave-uniform)
+        auto live = [&](int seq) { return seq % TPW < BASE || ((seq / TPW) >> 1) == wave; };
         ldb(0, br[0]);
 #pragma unroll
-        for (int u = 0; u < PD; ++u) lda(u, ar[u]);
+        for (int u = 0; u < PD; ++u) if (live(u)) lda(u, ar[u]);
 #pragma unroll
         for (int seq = 0; seq < NSEQ; ++seq) {
             const int st = seq / TPW, i = seq % TPW;
-            if (seq + PD < NSEQ) lda(seq + PD, ar[(seq + PD) % (PD + 1)]);
+            if (seq + PD < NSEQ && live(seq + PD)) lda(seq + PD, ar[(seq + PD) % (PD + 1)]);
             if (i == 0 && st + 1 < 8) ldb(st + 1, br[(st + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            if (!live(seq)) continue;
             const uint2 (&a)[4] = ar[seq % (PD + 1)];
             const uint2 (&b)[4] = br[st & 1];
             const wbf16x8 ah = __builtin_bit_cast(wbf16x8, make_uint4(a[0].x, a[0].y, a[1].x, a[1].y));
@@ -681,17 +687,31 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
         }
         cw_barrier();
     }
+    // the four partial sums of the shared tap: [wave][register][lane] behind the 4 KiB the data waves use for the bias sums
+    // (all staging buffers are free: every multiplying wave is past the last stage's barrier)
+    float* const tp = reinterpret_cast<float*>(smc + 8192);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tp[(wave * 16 + r) * 64 + lane] = acc[BASE][r];
     cw_barrier();                                                          // pairs with the D waves' two bias barriers
     cw_barrier();
+    const int k = k0 + li;
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        if (i >= tap_n) continue;
+    for (int i = 0; i < BASE; ++i) {
         float* out = p.out + ((int64_t)slab * p.ntaps + tap_lo + i) * p.C * p.K;
-        const int k = k0 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (c < p.C && k < p.K) out[(int64_t)c * p.K + k] = acc[i][r];
+        }
+    }
+    {   // wave w finishes registers 4 w .. 4 w + 3 of the shared tap (fixed order: partial of wave 0, 1, 2, 3)
+        float* out = p.out + ((int64_t)slab * p.ntaps + NTAPS - 1) * p.C * p.K;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 4 + q;
+            const float v = ((tp[(0 * 16 + r) * 64 + lane] + tp[(1 * 16 + r) * 64 + lane]) + tp[(2 * 16 + r) * 64 + lane]) + tp[(3 * 16 + r) * 64 + lane];
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (c < p.C && k < p.K) out[(int64_t)c * p.K + k] = v;
         }
     }
 }
