@@ -458,19 +458,33 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
 // ------------------------------------------------------------------------------------------------
 // Software-pipelined split-bf16 filter gradient (the cconv.hip structure applied to Conv2DBackpropFilter): stride-1 5x5 / 3x3
 // layers on feature maps of at least 8 x 16 pixels, one 32 x 32 (channel x filter) tile of the filter per workgroup.
-//   * waves 4-7 ("D"): the fp32 halo of x and the tile of dy of stage s+2 travel HBM -> LDS by LDS-DMA through buffer
-//     descriptors (out-of-image lanes read zeros), the pieces of stage s+1 are split into bf16 hi / lo planes LDS -> LDS; a wave
-//     converts exactly the pieces its own DMA wrote.  The bias gradient (column sums of dy) is accumulated on the way.
+//   * waves 4-7 ("D"): the fp32 halo of x and the tile of dy travel HBM -> registers through buffer descriptors (out-of-image
+//     lanes read zeros) two stages ahead, and are split into the bf16 hi / lo planes of stage s+1 while stage s is multiplied.
+//     The bias gradient (column sums of dy) is accumulated on the way.
 //   * waves 0-3 ("M"): each owns up to 7 taps of the filter tile, accumulators in registers over the whole slab of tiles;
 //     both operands come from the planes with the transposing read ds_read_b64_tr_b16 at compile-time offsets from ONE
 //     address register per tap (the 16-pixel step loop is unrolled), operands of the next tap in flight under the MFMAs.
 //   * one workgroup barrier per stage (= one 8 x 16-pixel tile); the per-slab partial filter leaves once, at the end.
-// LDS (5x5): 2 x (x planes 30 KiB + dy planes 16 KiB) + 46 KiB raw = 138 KiB: one workgroup per CU.
+// LDS (5x5): 2 x (x planes 30 KiB + dy planes 16 KiB) = 92 KiB: one workgroup per CU.
 struct CwParams {
     const float* img; const float* feat; float* out; float* bias_out;
     int N, H, W, C, img_ld, Ho, Wo, K, feat_ld;
     int pt, pl, tiles_h, tiles_w, ctiles, ntiles_total, tiles_per_slab, ntaps;
+    int dbg;             // MV3D_DBG bit 32: in-kernel stamps (diagnostics)
 };
+
+// In-kernel stamps (MV3D_DBG bit 32 only; cdna_hip_programming.md section 7): wave w of workgroup (blockIdx.x == 0, slab b < 128)
+// writes the shader clock of event k to w_stamps[(b * 8 + w) * 64 + k]; read back with mv3d_debug_cwgrad_stamps().  No output
+// value depends on them.
+constexpr int CW_NSTAMP = 64;
+__device__ unsigned long long w_stamps[128 * 8 * CW_NSTAMP];
+__device__ __forceinline__ void wstamp(bool on, int wave, int lane, int& k) {
+    if (on) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (lane == 0 && k < CW_NSTAMP && blockIdx.x == 0 && blockIdx.y < 128) w_stamps[((int)blockIdx.y * 8 + wave) * CW_NSTAMP + k] = t;
+        ++k;
+    }
+}
 
 __device__ __forceinline__ void cw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -485,7 +499,6 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
     constexpr int XPIECES = (HPIX + 7) / 8, NPIECES = XPIECES + 16;
     constexpr int PPW = (NPIECES + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smc[];
-    unsigned char* const raw = smc + 2 * BUF;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -510,92 +523,111 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
         const int64_t xb = (int64_t)p.N * p.H * p.W * p.img_ld * 4, fb = (int64_t)p.N * p.Ho * p.Wo * p.feat_ld * 4;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.img), 0, (int)(xb < 0x7fffffff ? xb : 0x7fffffff), 0x00020000);
         const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feat), 0, (int)(fb < 0x7fffffff ? fb : 0x7fffffff), 0x00020000);
-        // per-lane constants of this wave's pieces: x pieces first (halo pixels), then the dy pieces (tile pixels)
-        int voff[PPW], rc[PPW];                                       // byte offset from the stage origin; (row << 8 | column), 0x7fff00 = no pixel
+        // per-lane constants of this wave's pieces.  x pieces (halo pixels) and dy pieces (tile pixels) are numbered separately,
+        // wave w takes x pieces w, w + 4, ... and dy pieces w, w + 4, w + 8, w + 12: which operand a slot holds is a compile-time
+        // fact, so the loads below are twelve unconditional instructions (a slot that can be either made hipcc branch between
+        // two descriptors and wait for vmcnt(0) at every join)
+        constexpr int NXJ = (XPIECES + 3) / 4, NFJ = 4;
+        int xvoff[NXJ], xrc[NXJ];                                     // byte offset from the stage origin; (row << 8 | column), 0x7fff00 = no pixel
+        int fvoff[NFJ], frc[NFJ];
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int pc = dwv + 4 * j;
-            if (pc < XPIECES) {
-                const int pix = pc * 8 + psub;
-                const int hr = pix / HC, hc = pix - hr * HC;
-                voff[j] = ((hr * p.W + hc) * p.img_ld + c4 * 4) * 4;
-                rc[j] = pix < HPIX ? (hr << 8 | hc) : 0x7fff00;
-            } else {
-                const int pq = (pc - XPIECES) * 8 + psub;
-                const int r = pq >> 4, c = pq & 15;
-                voff[j] = ((r * p.Wo + c) * p.feat_ld + c4 * 4) * 4;
-                rc[j] = pc < NPIECES ? (r << 8 | c) : 0x7fff00;
-            }
+        for (int j = 0; j < NXJ; ++j) {
+            const int pix = (dwv + 4 * j) * 8 + psub;
+            const int hr = pix / HC, hc = pix - hr * HC;
+            xvoff[j] = ((hr * p.W + hc) * p.img_ld + c4 * 4) * 4;
+            xrc[j] = pix < HPIX ? (hr << 8 | hc) : 0x7fff00;
+        }
+#pragma unroll
+        for (int j = 0; j < NFJ; ++j) {
+            const int pq = (dwv + 4 * j) * 8 + psub;
+            const int r = pq >> 4, c = pq & 15;
+            fvoff[j] = ((r * p.Wo + c) * p.feat_ld + c4 * 4) * 4;
+            frc[j] = r << 8 | c;
         }
         const bool xch_ok = c0 + c4 * 4 < p.C, fch_ok = k0 + c4 * 4 < p.K;
-        auto issue = [&](int stage) {
+        // fp32 pieces of a stage: HBM -> registers (16 bytes per lane and piece; lanes outside the image / tensor read zeros through
+        // the descriptor's bounds check), two stages ahead of the one being converted
+        typedef unsigned int wu4 __attribute__((ext_vector_type(4)));
+        struct Regs { wu4 x[NXJ]; wu4 f[NFJ]; };
+        auto fetch = [&](int stage, Regs& R) {
             int n, oh0, ow0;
             origin(stage, n, oh0, ow0);
             const int ih0 = oh0 - p.pt, iw0 = ow0 - p.pl;
             const int xso = (((n * p.H + ih0) * p.W + iw0) * p.img_ld + c0) * 4;
             const int fso = (((n * p.Ho + oh0) * p.Wo + ow0) * p.feat_ld + k0) * 4;
 #pragma unroll
-            for (int j = 0; j < PPW; ++j) {
-                const int pc = dwv + 4 * j;
-                if (pc < NPIECES) {
-                    const int r = rc[j] >> 8, c = rc[j] & 255;
-                    if (pc < XPIECES) {
-                        const bool ok = xch_ok && (unsigned)(ih0 + r) < (unsigned)p.H && (unsigned)(iw0 + c) < (unsigned)p.W;
-                        const int off = ok ? voff[j] + xso : (int)0x80000000;      // a named value: with the conditional inline hipcc (ROCm 7.2) drops the kernel's host stub
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(raw + pc * 1024), 16, off, 0, 0, 0);
-                    } else {
-                        const bool ok = fch_ok && oh0 + r < p.Ho && ow0 + c < p.Wo;
-                        const int off = ok ? voff[j] + fso : (int)0x80000000;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (__attribute__((address_space(3))) void*)(raw + pc * 1024), 16, off, 0, 0, 0);
-                    }
-                }
+            for (int j = 0; j < NXJ; ++j) {
+                const int r = xrc[j] >> 8, c = xrc[j] & 255;
+                const bool ok = xch_ok && (unsigned)(ih0 + r) < (unsigned)p.H && (unsigned)(iw0 + c) < (unsigned)p.W;      // the no-pixel marker is row 32767
+                const int off = ok ? xvoff[j] + xso : (int)0x80000000;
+                R.x[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NFJ; ++j) {
+                const int r = frc[j] >> 8, c = frc[j] & 255;
+                const bool ok = fch_ok && oh0 + r < p.Ho && ow0 + c < p.Wo;
+                const int off = ok ? fvoff[j] + fso : (int)0x80000000;
+                R.f[j] = __builtin_amdgcn_raw_buffer_load_b128(fr, off, 0, 0);
             }
         };
-        float4 bsum[4];
+        // bias-gradient partial sums, one per dy piece slot (compile-time indices: with a run-time index they lived in scratch, and
+        // a scratch access waits for vmcnt(0))
+        float4 bsum[NFJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto convert = [&](int stage) {
+        for (int j = 0; j < NFJ; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto convert = [&](int stage, const Regs& R) {
             unsigned char* const b = smc + (stage & 1) * BUF;
-            int fj = 0;
 #pragma unroll
-            for (int j = 0; j < PPW; ++j) {
-                const int pc = dwv + 4 * j;
-                if (pc < NPIECES) {
-                    const float4 v = *reinterpret_cast<const float4*>(raw + pc * 1024 + lane * 16);
-                    uint2 hi, lo;
-                    wsplit4(v, hi, lo);
-                    if (pc < XPIECES) {
-                        if (rc[j] != 0x7fff00) {
-                            unsigned char* d = b + (pc * 8 + psub) * 64 + c4 * 8;
-                            *reinterpret_cast<uint2*>(d) = hi;
-                            *reinterpret_cast<uint2*>(d + XPL) = lo;
-                        }
-                    } else {
-                        unsigned char* d = b + 2 * XPL + ((pc - XPIECES) * 8 + psub) * 64 + c4 * 8;
-                        *reinterpret_cast<uint2*>(d) = hi;
-                        *reinterpret_cast<uint2*>(d + FPL) = lo;
-                        // bias gradient: this lane always sees filters k0 + 4 c4 .. + 3 (out-of-range lanes were loaded as zeros)
-                        if (fj < 4) { bsum[fj].x += v.x; bsum[fj].y += v.y; bsum[fj].z += v.z; bsum[fj].w += v.w; }
-                        ++fj;
-                    }
+            for (int j = 0; j < NXJ; ++j) {
+                const float4 v = make_float4(__uint_as_float(R.x[j][0]), __uint_as_float(R.x[j][1]), __uint_as_float(R.x[j][2]), __uint_as_float(R.x[j][3]));
+                uint2 hi, lo;
+                wsplit4(v, hi, lo);
+                if (xrc[j] != 0x7fff00) {
+                    unsigned char* d = b + ((dwv + 4 * j) * 8 + psub) * 64 + c4 * 8;
+                    *reinterpret_cast<uint2*>(d) = hi;
+                    *reinterpret_cast<uint2*>(d + XPL) = lo;
                 }
             }
+#pragma unroll
+            for (int j = 0; j < NFJ; ++j) {
+                const float4 v = make_float4(__uint_as_float(R.f[j][0]), __uint_as_float(R.f[j][1]), __uint_as_float(R.f[j][2]), __uint_as_float(R.f[j][3]));
+                uint2 hi, lo;
+                wsplit4(v, hi, lo);
+                unsigned char* d = b + 2 * XPL + ((dwv + 4 * j) * 8 + psub) * 64 + c4 * 8;
+                *reinterpret_cast<uint2*>(d) = hi;
+                *reinterpret_cast<uint2*>(d + FPL) = lo;
+                // bias gradient: this lane always sees filters k0 + 4 c4 .. + 3 (out-of-range lanes were loaded as zeros)
+                bsum[j].x += v.x; bsum[j].y += v.y; bsum[j].z += v.z; bsum[j].w += v.w;
+            }
         };
+        const bool stp = (p.dbg & 32) != 0;
+        int sk = 0;
+        wstamp(stp, wave, lane, sk);                                       // 0: start
+        // Stage s is multiplied while stage s + 1 is converted from registers fetched two stages earlier and stage s + 3 is
+        // requested: a request has two whole stages to land (the LDS-DMA form of round 2's first version had one raw buffer, hence
+        // one stage in flight: the data waves waited 8.5 k cycles of a 12 k-cycle stage for it -- stamps, profiles/r02_e_*).
+        Regs R0, R1;
+        auto clamp = [&](int st) { return st < nstages ? st : nstages - 1; };      // past the end: refetch the last tile (never converted)
         if (nstages > 0) {
-            issue(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            convert(0);
-            if (nstages > 1) issue(1);
+            fetch(0, R0);
+            fetch(clamp(1), R1);
+            convert(0, R0);
+            fetch(clamp(2), R0);
         }
         cw_barrier();
-        for (int s = 0; s < nstages; ++s) {
-            if (s + 1 < nstages) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                convert(s + 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (s + 2 < nstages) issue(s + 2);
-            }
+        wstamp(stp, wave, lane, sk);                                       // 1: prologue barrier passed
+        for (int s = 0; s < nstages; s += 2) {
+            if (s + 1 < nstages) convert(s + 1, R1);
+            wstamp(stp, wave, lane, sk);                                   // 2 + 4k: converted
+            fetch(clamp(s + 3), R1);
             cw_barrier();
+            wstamp(stp, wave, lane, sk);                                   // 3 + 4k: barrier passed
+            if (s + 1 >= nstages) break;
+            if (s + 2 < nstages) convert(s + 2, R0);
+            wstamp(stp, wave, lane, sk);                                   // 4 + 4k: converted
+            fetch(clamp(s + 4), R0);
+            cw_barrier();
+            wstamp(stp, wave, lane, sk);                                   // 5 + 4k: barrier passed
         }
         // bias gradient of this slab: 256 lanes x 4 float4 partial sums -> 32 column sums, fixed order (buffers are free now)
         cw_barrier();                                                      // M waves are past their last reads
@@ -641,6 +673,9 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     cw_barrier();                                                          // stage 0 is in buffer 0
+    const bool stp = (p.dbg & 32) != 0;
+    int stk = 0;
+    wstamp(stp, wave, lane, stk);                                          // 0: first stage starts
     for (int s = 0; s < nstages; ++s) {
         const unsigned char* const buf = smc + (s & 1) * BUF;
         const unsigned char* va[TPW];
@@ -685,7 +720,9 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
         }
+        wstamp(stp, wave, lane, stk);                                      // 1 + 2s: taps done
         cw_barrier();
+        wstamp(stp, wave, lane, stk);                                      // 2 + 2s: barrier passed
     }
     // the four partial sums of the shared tap: [wave][register][lane] behind the 4 KiB the data waves use for the bias sums
     // (all staging buffers are free: every multiplying wave is past the last stage's barrier)
@@ -740,6 +777,7 @@ static int cwgrad_plan(const mv3d_conv_geom* g, CwParams* out) {
     p.N = g->N; p.H = g->H; p.W = g->W; p.C = g->C; p.img_ld = g->img_ld; p.Ho = g->Ho; p.Wo = g->Wo; p.K = g->K; p.feat_ld = g->feat_ld;
     p.tiles_h = g->Ho / 8; p.tiles_w = g->Wo / 16; p.ctiles = g->C / 32; p.ntaps = g->kh * g->kw;
     p.ntiles_total = g->N * p.tiles_h * p.tiles_w;
+    { static int d = -1; if (d < 0) { const char* e = getenv("MV3D_DBG"); d = e ? atoi(e) : 0; } p.dbg = d; }
     static int min_tiles = -1;
     if (min_tiles < 0) { const char* e = getenv("MV3D_CW_MINTILES"); min_tiles = e ? atoi(e) : 64; }
     if (p.ntiles_total < min_tiles) return 0;
@@ -758,7 +796,7 @@ static int cwgrad_launch_t(const mv3d_conv_geom* g, CwParams p, int nslab, void*
     const double bytes = 4.0 * ((double)g->N * g->H * g->W * g->C + (double)g->N * g->Ho * g->Wo * g->K + (double)g->kh * g->kw * g->C * g->K);
     dim3 grid(p.ctiles * (g->K / 32), nslab);
     constexpr int hpix = (7 + KW) * (15 + KW);
-    const size_t lds = 2 * (size_t)(2 * hpix * 64 + 2 * 128 * 64) + (size_t)((hpix + 7) / 8 + 16) * 1024;
+    const size_t lds = 2 * (size_t)(2 * hpix * 64 + 2 * 128 * 64);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cwgrad_kernel<KW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -935,3 +973,10 @@ int wgrad_tile_launch_erased(const mv3d_conv_geom* g, const void* img, const voi
 }
 
 }  // namespace mv3d
+
+extern "C" int mv3d_debug_cwgrad_stamps(void* dst, size_t bytes) {
+    if (!dst || bytes > sizeof(unsigned long long) * 128 * 8 * mv3d::CW_NSTAMP) return mv3d::fail(MV3D_E_INVAL, "mv3d_debug_cwgrad_stamps: bad buffer");
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv3d::w_stamps), bytes, 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_debug_cwgrad_stamps: %s", hipGetErrorString(e));
+    return MV3D_OK;
+}

@@ -276,6 +276,8 @@ int mv3d_plan_op_info(const mv3d_plan* p, int i, const char** name, double* flop
 /* Diagnostics: copies the in-kernel clock stamps of the pipelined convolution kernel (csrc/cconv.hip; written only when the
  * environment sets MV3D_DBG bit 32) to host memory: [256 workgroups][8 waves][64 events] uint64 (tools/cconv_stamps.py). */
 int mv3d_debug_cconv_stamps(void* host_dst, size_t bytes);
+/* the same for the pipelined filter-gradient kernel (cwgrad): [128 slabs][8 waves][64 events] of the workgroups with blockIdx.x == 0 */
+int mv3d_debug_cwgrad_stamps(void* host_dst, size_t bytes);
 
 #ifdef __cplusplus
 }

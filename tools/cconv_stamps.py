@@ -74,3 +74,16 @@ if int(os.environ.get('MV3D_DBG', '0')) & 32 and not wgrad:
             print("  wave %d (%s):" % (wv, 'M' if wv < 4 else 'D'), ' '.join("%6d" % v for v in np.diff(np.concatenate([[0], row]))[:40]))
     m_end = s[:, 0, :].max(axis=1) - t0
     print("last stamp of wave 0 per workgroup: min %d median %d max %d cycles (100 MHz realtime? no: shader clock)" % (m_end.min(), np.median(m_end), m_end.max()))
+if int(os.environ.get('MV3D_DBG', '0')) & 32 and wgrad:
+    NS = 64
+    buf = np.zeros(128 * 8 * NS, np.uint64)
+    rc = L.dll.mv3d_debug_cwgrad_stamps(buf.ctypes.data, buf.nbytes)
+    assert rc == 0, rc
+    s = buf.reshape(128, 8, NS).astype(np.int64)
+    t0 = s[:, :, 0][s[:, :, 0] > 0].min()
+    for wg in (0, 1, 64, 127):
+        print("slab", wg)
+        for wv in (0, 3, 4, 7):
+            row = s[wg, wv]
+            row = row[row > 0] - t0
+            print("  wave %d (%s):" % (wv, 'M' if wv < 4 else 'D'), ' '.join("%6d" % v for v in np.diff(np.concatenate([[0], row]))[:44]))
