@@ -471,24 +471,29 @@ __global__ __launch_bounds__(256) void fc_wgrad_b3_kernel(const FcWgradParams p)
         for (int t = 0; t < 2; ++t) {
             const int k = k0 + wt * 64 + t * 32 + li;
             if constexpr (ADAM) {
-                // the gradient never goes to HBM: parameter and slots are read, updated and written back here, four rows in
-                // flight per lane (12 loads before the first store)
+                // the gradient never goes to HBM: parameter and slots are read, updated and written back here.  All sixteen rows of
+                // an accumulator tile are requested before the first store (48 loads in flight per lane): vmcnt retires in order and
+                // counts stores, so with four rows per round (round 2's first version) every round paid a load round trip behind the
+                // previous round's store acknowledgements -- sixteen per workgroup, 95 us per 67 MB matrix; now four, 86 us = 4.8 TB/s.
+                // (Requesting the next tile before storing this one needs a second register set: 197 VGPRs, one workgroup fewer per
+                // CU, measured slower.)
+                {
+                    float pv[16], mv[16], vv[16];
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    float pv[4], mv[4], vv[4];
-                    int64_t idx[4];
-                    bool ok[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c = c0 + ws * 64 + s * 32 + j + 8 * r4 + 4 * lh;
-                        ok[j] = c < p.C && k < p.K;
-                        idx[j] = ok[j] ? (int64_t)c * p.K + k : 0;
-                        pv[j] = p.dW[idx[j]]; mv[j] = p.M1[idx[j]]; vv[j] = p.V2[idx[j]];
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = c0 + ws * 64 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int64_t idx = (c < p.C && k < p.K) ? (int64_t)c * p.K + k : 0;
+                        pv[r] = p.dW[idx]; mv[r] = p.M1[idx]; vv[r] = p.V2[idx];
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        adam_elem(acc[s][t][4 * r4 + j] * gscale, pv[j], mv[j], vv[j], alpha, omb1, omb2, eps);
-                        if (ok[j]) { p.dW[idx[j]] = pv[j]; p.M1[idx[j]] = mv[j]; p.V2[idx[j]] = vv[j]; }
+                    for (int r = 0; r < 16; ++r) adam_elem(acc[s][t][r] * gscale, pv[r], mv[r], vv[r], alpha, omb1, omb2, eps);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = c0 + ws * 64 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (c < p.C && k < p.K) {
+                            const int64_t idx = (int64_t)c * p.K + k;
+                            p.dW[idx] = pv[r]; p.M1[idx] = mv[r]; p.V2[idx] = vv[r];
+                        }
                     }
                 }
             } else {

@@ -617,6 +617,10 @@ __global__ __launch_bounds__(512) void cwgrad_kernel(const CwParams p) {
         cw_barrier();
         wstamp(stp, wave, lane, sk);                                       // 1: prologue barrier passed
         for (int s = 0; s < nstages; s += 2) {
+#ifdef CW_EXP_WAITSTAMP
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NXJ + NFJ) : "memory");
+            wstamp(stp, wave, lane, sk);
+#endif
             if (s + 1 < nstages) convert(s + 1, R1);
             wstamp(stp, wave, lane, sk);                                   // 2 + 4k: converted
             fetch(clamp(s + 3), R1);
