@@ -500,6 +500,7 @@ class Graph:
         self.pipeline_fc = os.environ.get('MV3D_PIPELINE_FCADAM', '1') != '0'
         # data parallel, sharded optimiser: all-gathers of buckets first read at forward launch >= pipeline_dp_min_idx are deferred
         self.pipeline_dp = os.environ.get('MV3D_PIPELINE_DP', '1') != '0'
+        self.dp_join = os.environ.get('MV3D_DP_JOIN', '0') != '0'      # 1: the main stream joins the side streams at every bucket boundary (round-1 behaviour)
         self.pipeline_dp_min_idx = 8
         self.fc_after_wgrads = os.environ.get('MV3D_FC_AFTER_WGRADS', '0') != '0'      # hold the fused fc optimiser until the conv filter gradients are done
         self._fused_nodes = []
@@ -1049,12 +1050,17 @@ class Graph:
         begin = 0
         late = []                       # [(first forward launch that reads the bucket, lo, slice length)]
         for end, lo, hi in self.grad_buckets:
-            self.lib.plan_run_range_multi(self.plan_bwd, begin, end, main, sides, ns, 0)      # joins the side streams
+            # the segment's filter-gradient launches stay on their side streams: only the COMMUNICATION stream waits for them (the
+            # main stream goes straight on with the next layers' data gradients instead of idling behind an 80 us fc filter gradient
+            # at every bucket boundary)
+            self.lib.plan_run_range_multi(self.plan_bwd, begin, end, main, sides, ns, 1 if (on_gpu and not self.dp_join) else 0)
             begin = end
             if hi <= lo:
                 continue
             if on_gpu:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+                for q in (self.side_streams or []):
+                    self.comm_stream.wait_stream(q)
                 ctx = torch.cuda.stream(self.comm_stream)      # a torch.distributed communicator takes the current stream
                 ctx.__enter__()
             if self.dp_mode == 'sharded' and with_adam:
@@ -1077,7 +1083,10 @@ class Graph:
             if on_gpu:
                 ctx.__exit__(None, None, None)
         if on_gpu:
-            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)      # every reduce-scatter, Adam slice and early all-gather
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.comm_stream)                # every reduce-scatter, Adam slice and early all-gather
+            for q in (self.side_streams or []):              # (and any filter gradient behind the last bucket's boundary)
+                cur.wait_stream(q)
         if late:
             late.sort()
             if on_gpu:
