@@ -711,7 +711,7 @@ static int launch_bconvu_t(const IgemmParams& p, const HconvExtra& x, dim3 grid,
     name = intern_label("bconvu<%s,%s%dpx,N%d%s>", NTAPS == 25 ? "5x5" : "3x3", x.G > 1 ? "small-img," : "", 32 * MT * WAVES, 32 * NT,
                         x.ksplit > 1 ? ",ksplit" : "");
     static int wg_per_cu = -1;
-    if (wg_per_cu < 0) { const char* e = getenv("MV3D_BC_PERSIST"); wg_per_cu = e ? atoi(e) : 2; }
+    if (wg_per_cu < 0) { const char* e = getenv("MV3D_BC_PERSIST"); wg_per_cu = e ? atoi(e) : 3; }      // 3 where LDS allows (52 KB stride-2 tiles): +1 % on the step over 2
     dim3 pg = grid;
     if (wg_per_cu > 0) {
         const int by_lds = std::max(1, (int)((160 * 1024) / std::max<size_t>(lds, 1)));
