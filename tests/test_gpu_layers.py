@@ -247,6 +247,42 @@ def test_pipelined_fc_optimiser_equals_joined_step(monkeypatch):
     np.testing.assert_array_equal(res[0][3][:8], res[0][3][8:])          # both device Adam records advanced alike
 
 
+def test_held_fc_optimiser_schedule_equals_joined_step(monkeypatch):
+    """MV3D_FC_AFTER_WGRADS=1: the fused fc optimiser launches are left out of the reverse plan's run (MV3D_RUN_HOLD_CLASS2) and issued
+    with mv3d_plan_run_side behind the conv filter gradients -- an opt-in schedule, held bit-identical to the joined one."""
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    from tests.synth import appflow_feeds
+    feeds = appflow_feeds(np.random.default_rng(6), 8)
+    res = []
+    for held in ('1', '0'):
+        monkeypatch.setenv('MV3D_FC_AFTER_WGRADS', held)
+        monkeypatch.setenv('MV3D_PIPELINE_FCADAM', held)
+        model = AppearanceFlowModel({'batch_size': 8, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda')
+        g = model.graph
+        for _ in range(3):
+            model.feed(**feeds)
+            g.train_step()
+        torch.cuda.synchronize()
+        g.settle()
+        res.append((g.params.cpu().numpy().copy(), g.adam_m.cpu().numpy().copy(), g.adam_v.cpu().numpy().copy()))
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_wgrad_cu_override_changes_only_the_summation_order():
+    """mv3d_set_wgrad_cus: the partial-filter slabs of a conv filter gradient spread over 64 / 256 CUs instead of the default 128 --
+    same result up to fp32 summation order, and the setter returns the previous value."""
+    case = LC.APPFLOW_B64[1]
+    assert L().set_wgrad_cus(64) == 0
+    try:
+        run_conv_case(case)
+        assert L().set_wgrad_cus(256) == 64
+        run_conv_case(case)
+    finally:
+        L().set_wgrad_cus(0)
+    assert L().set_wgrad_cus(0) == 0
+
+
 def test_exact_fp32_rung_at_batch_64():
     """the MV3D_DISABLE=4096 twins (exact fp32 MFMA) of the two layers that carry the step, at the benchmarked batch"""
     old = L().set_diagnostics(4096)
