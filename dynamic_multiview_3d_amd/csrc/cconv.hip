@@ -30,8 +30,6 @@ namespace mv3d {
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
 
-__device__ float4 c_zero16[4];        // 64 bytes of zeros in the code object: source of out-of-image LDS-DMA lanes
-
 // In-kernel stamps (diagnostics, MV3D_DBG bit 32 only; cdna_hip_programming.md section 7): wave `w` of workgroup `b` writes the
 // shader clock of event k to c_stamps[(b * 8 + w) * CC_NSTAMP + k]; tools/cconv_stamps.py reads them back through
 // mv3d_debug_cconv_stamps().  No output value depends on them.
@@ -66,6 +64,17 @@ __device__ __forceinline__ void cbarrier() { asm volatile("s_waitcnt lgkmcnt(0)\
 #ifndef CC_LA5
 #define CC_LA5 3
 #endif
+// smallest ring depth R of the saved-output registers such that the loads of group g + R (top of tap ts(g + R) - D) come
+// after the stores of group g (middle of tap ts(g)), with ts(g) = D + g * (NTAPS - D) / NG
+constexpr int cc_gr_depth(int ntaps, int d, int ng) {
+    for (int r = 1; r < ng; ++r) {
+        bool ok = true;
+        for (int g = 0; g + r < ng; ++g)
+            if (!((d + ((g + r) * (ntaps - d)) / ng) - d > d + (g * (ntaps - d)) / ng)) ok = false;
+        if (ok) return r;
+    }
+    return ng;
+}
 constexpr int CC_HC = 20;             // halo pitch in pixels (15 + kw rounded up to a multiple of 4)
 
 template <int KW, bool REV, bool HAS_G, int U, int D, int MT>
@@ -236,7 +245,15 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(HAS_G ? p.gref : p.Out), 0,
                                                                              (int)(r_bytes < 0x7fffffff ? r_bytes : 0x7fffffff), 0x00020000);
     int ptile = 0;                                                     // first pixel of the previous tile (wave-uniform)
-    float gr[2][4];
+    // store schedule of the tap loop: group g leaves in the middle of tap ts(g); its saved-output loads are issued at the top of
+    // tap ts(g) - D, in front of that tap's filter look-ahead loads, so the in-order vmcnt wait that covers the filter ring also
+    // covers them.  The saved-output registers are a ring of GRD groups: slot g % GRD must not be refilled before group g has
+    // left, i.e. ts(g + GRD) - D > ts(g) for every g (3x3 with 16 x 16 tiles needs four slots, every other instance two).
+    constexpr int NG = 4 * MT;                                         // store groups per tile and wave
+    auto ts_of = [](int g8) { return D + (g8 * (NTAPS - D)) / NG; };
+    constexpr int GRD = cc_gr_depth(NTAPS, D, NG);
+    static_assert(GRD >= 1 && GRD <= NG, "saved-output ring");
+    float gr[GRD][4];
     auto group_pix = [&](int g8, int j) {                              // pixel offset of element j of group g8 inside the tile, minus the lane part
         const int m = g8 >> 2, grp = g8 & 3;
         return (2 * m + (grp >> 1)) * p.Wc + 8 * (grp & 1) + j;
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
         if constexpr (HAS_G) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                gr[g8 & 1][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, ref_lane, (ptile + group_pix(g8, j)) * p.g_ld * 4, 0));
+                gr[g8 % GRD][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, ref_lane, (ptile + group_pix(g8, j)) * p.g_ld * 4, 0));
             }
         }
     };
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             float v = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
             v = (is_relu && xv < 0.0f) ? -0.0f : v;
             if constexpr (HAS_G) {
-                const float y = gr[g8 & 1][j];
+                const float y = gr[g8 % GRD][j];
                 const bool neg = g_relu ? (__float_as_uint(y) >> 31) != 0 : y < 0.0f;
                 const float sgn = y > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f);
                 v *= g1 + g2 * sgn;
@@ -265,11 +282,6 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, out_lane, (ptile + group_pix(g8, j)) * p.c_ld * 4, 0);
         }
     };
-    // store schedule of the tap loop: group g leaves at tap ts(g); its saved-output loads are issued D taps earlier, in front
-    // of that tap's filter look-ahead loads, so the in-order vmcnt wait that covers the filter ring also covers them
-    constexpr int NG = 4 * MT;                                         // store groups per tile and wave
-    auto ts_of = [](int g8) { return D + (g8 * (NTAPS - D)) / NG; };
-
 #pragma unroll
     for (int u = 0; u < D; ++u) load_b(ring[u], u, 0);
     cbarrier();                                                        // stage 0 is in buffer 0
@@ -310,38 +322,10 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
             {   // look-ahead tap: this chunk, or the first taps of the next stage's chunk
                 const int tn = t + D;
                 const int ccn = cc + 1 < chunks ? cc + 1 : 0;
-#ifdef CC_EXP_NOB
-                if (s == 0 && t < 2)
-#endif
                 load_b(ring[tn % U], tn < NTAPS ? tn : tn - NTAPS, tn < NTAPS ? cc : ccn);
             }
             __builtin_amdgcn_sched_barrier(0);                         // keep the look-ahead load here (hipcc sinks it to its first use)
             const BSet& f = ring[t % U];
-#if defined(CC_EXP_ILV)
-            static_assert(MT == 2, "experiment only");
-            // the two pixel groups' accumulator chains interleaved: consecutive MFMAs never depend on each other
-#pragma unroll
-            for (int sk = 0; sk < 2; ++sk) {
-                const cbf16x8 bh = __builtin_bit_cast(cbf16x8, f.b[sk][0]), bl = __builtin_bit_cast(cbf16x8, f.b[sk][1]);
-                const cbf16x8 ah0 = __builtin_bit_cast(cbf16x8, a[0][sk][0]), al0 = __builtin_bit_cast(cbf16x8, a[0][sk][1]);
-                const cbf16x8 ah1 = __builtin_bit_cast(cbf16x8, a[1][sk][0]), al1 = __builtin_bit_cast(cbf16x8, a[1][sk][1]);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1], 0, 0, 0);
-                if (t + 1 < NTAPS) { read_a(t + 1 < NTAPS ? t + 1 : t, 0, sk); read_a(t + 1 < NTAPS ? t + 1 : t, 1, sk); }
-                if constexpr (PEND) {
-                    if (sk == 0) {
-#pragma unroll
-                        for (int g8 = 0; g8 < NG; ++g8)
-                            if (t == ts_of(g8)) fin_group(g8);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#else
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
@@ -353,9 +337,7 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
                     // refill this operand pair for the next tap right here: nine MFMAs (~290 cycles) lie between this read and its
                     // first use; pinned, because hipcc otherwise sinks the reads down to their uses
-#ifndef CC_EXP_NOA
                     if (t + 1 < NTAPS) read_a(t + 1 < NTAPS ? t + 1 : t, m, sk);
-#endif
                     if constexpr (PEND) {
                         if (sk == 0 && m == MT - 1) {
 #pragma unroll
@@ -365,7 +347,6 @@ __global__ __launch_bounds__(512) void cconv_kernel(const IgemmParams p, const H
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
         }
     };
 

@@ -1727,7 +1727,8 @@ int mv3d_fc_wgrad_adam(int B, int in, int out, const void* x, int x_ld, const vo
                        void* db, const void* adam_state, void* stream) {
     if (B <= 0 || in <= 0 || out <= 0 || !x || !dy || !M || !adam_m || !adam_v || !adam_state || x_ld < in || dy_ld < out)
         return fail(MV3D_E_INVAL, "mv3d_fc_wgrad_adam: bad arguments");
-    int rc = try_fc_wgrad_adam(B, in, out, x, x_ld, dy, dy_ld, M, adam_m, adam_v, db, adam_state, stream, "mv3d_fc_wgrad_adam");
+    // one predicate with mv3d_fc_wgrad_adam_supported (plus the pointer alignment only this call can see)
+    int rc = mv3d_fc_wgrad_adam_supported(B, in, out, x_ld, dy_ld) ? try_fc_wgrad_adam(B, in, out, x, x_ld, dy, dy_ld, M, adam_m, adam_v, db, adam_state, stream, "mv3d_fc_wgrad_adam") : 1;
     if (rc == 1) return fail(MV3D_E_UNSUPPORTED, "mv3d_fc_wgrad_adam: %d x %d x %d is not a layer of the fused kernel (use mv3d_fc_wgrad + mv3d_adam_step_dev)", B, in, out);
     return rc;
 }

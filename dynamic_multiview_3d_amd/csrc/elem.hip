@@ -4,8 +4,48 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 
 namespace mv3d {
+
+// ---------------------------------------------------------------- fixed-order loss sums
+// A loss kernel ends with one term per workgroup.  They used to meet in a float atomicAdd on the loss word, whose order -- and so
+// the last bits of the scalar -- changed from run to run.  Now every workgroup parks its term in its own word of a scratch row
+// (an agent-scope atomic exchange: performed at the memory side, visible to every XCD), takes a ticket, and the workgroup that
+// draws the last ticket sums the row in index order and adds ONE value to the loss word: launches of a stream add in stream
+// order, so the scalar is reproducible bit for bit.  Rows are handed out round-robin per launch (a recorded launch keeps its row).
+constexpr int LOSS_ROWS = 32, LOSS_MAXB = 1024;
+__device__ unsigned g_loss_part[LOSS_ROWS][LOSS_MAXB];
+__device__ unsigned g_loss_ticket[LOSS_ROWS];
+
+static int next_loss_row() {
+    static std::atomic<unsigned> n{0};
+    return (int)(n.fetch_add(1) % LOSS_ROWS);
+}
+
+// every thread of a 256-thread workgroup calls this; thread 0 passes the workgroup's term
+__device__ __forceinline__ void loss_combine(float term, float* loss, int row) {
+    __shared__ unsigned s_last;
+    __shared__ float s_w[4];
+    if (threadIdx.x == 0) {
+        (void)__hip_atomic_exchange(&g_loss_part[row][blockIdx.x], __float_as_uint(term), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the exchange has been performed before the ticket is drawn
+        const unsigned t = __hip_atomic_fetch_add(&g_loss_ticket[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float sum = 0.f;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256)
+        sum += __uint_as_float(__hip_atomic_fetch_or(&g_loss_part[row][i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(loss, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+        __hip_atomic_store(&g_loss_ticket[row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // ---------------------------------------------------------------- warp_pts_layer + resample_layer
 // tf_utils.py:35-52 + tf.contrib.resampler.  Output pixel (i,j):
@@ -82,7 +122,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleParams p) {
 // pass (the appearance-flow head: gen is only consumed by the loss, so dgen never needs to exist in HBM).
 struct ResampleTileParams {
     const float* src; const float* flow; const float* aux;     // aux: dgen (MODE 1) or target (MODE 2), pixel stride aux_ld
-    float* warp; float* gen; float* dflow; float* loss;
+    float* warp; float* gen; float* dflow; float* loss; int loss_row;
     int N, H, W, Hs, Ws, flow_ld, aux_ld, dflow_ld, kind;
     float weight;
     int tiles_i, tiles_j, n_tiles;
@@ -208,7 +248,7 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const ResampleTilePa
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
         if ((threadIdx.x & 63) == 0) s_xy[0][threadIdx.x >> 6] = sum;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(p.loss, (s_xy[0][0] + s_xy[0][1] + s_xy[0][2] + s_xy[0][3]) * (p.weight * inv_pix));
+        loss_combine((s_xy[0][0] + s_xy[0][1] + s_xy[0][2] + s_xy[0][3]) * (p.weight * inv_pix), p.loss, p.loss_row);
     }
 }
 
@@ -235,7 +275,7 @@ struct PixelLossParams {
     const float* b; int b_ld; float b_scale;
     const float* mask; int mask_ld;
     int kind; float weight;
-    float* loss; float* grad; int grad_ld;
+    float* loss; float* grad; int grad_ld; int loss_row;
 };
 
 // a, b, grad: [pixels][ch] views with pixel strides *_ld (channel slices of wider tensors, mv3d/nobg_dm.py:85-92);
@@ -259,13 +299,13 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(const PixelLossParams p
     __shared__ float s_part[4];
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(p.loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (p.weight / (float)p.pixels));
+    loss_combine((s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (p.weight / (float)p.pixels), p.loss, p.loss_row);
 }
 
 // dense, unmasked, unscaled operands (the appearance-flow loss): 16-byte loads / stores over the flat index
 __global__ __launch_bounds__(256) void pixel_loss_dense_kernel(int64_t total4, int64_t pixels, const float4* __restrict__ a,
                                                               const float4* __restrict__ b, int kind, float weight, float* loss,
-                                                              float4* __restrict__ grad) {
+                                                              float4* __restrict__ grad, int loss_row) {
     const float gscale = (kind == 2 ? 2.0f : 1.0f) * weight / (float)pixels;
     float sum = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
@@ -283,7 +323,7 @@ __global__ __launch_bounds__(256) void pixel_loss_dense_kernel(int64_t total4, i
     __shared__ float s_part[4];
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (weight / (float)pixels));
+    loss_combine((s_part[0] + s_part[1] + s_part[2] + s_part[3]) * (weight / (float)pixels), loss, loss_row);
 }
 
 // raw uint8 image bytes -> float32 / 255 (read_tf_records.py:111: tf.cast(image, tf.float32) / 255.0), four pixels' worth per lane
@@ -469,6 +509,7 @@ int mv3d_warp_resample_loss(int N, int H, int W, int Hs, int Ws, int C, const vo
     t.src = (const float*)src; t.flow = (const float*)flow; t.aux = (const float*)target; t.aux_ld = target_ld;
     t.warp = (float*)warp_out; t.gen = (float*)gen; t.dflow = (float*)dflow; t.loss = (float*)loss_accum;
     t.N = N; t.H = H; t.W = W; t.Hs = Hs; t.Ws = Ws; t.flow_ld = flow_ld; t.dflow_ld = dflow_ld; t.kind = kind; t.weight = weight;
+    t.loss_row = next_loss_row();
     static const int max_blocks = getenv("MV3D_RL_BLOCKS") ? atoi(getenv("MV3D_RL_BLOCKS")) : 512;
     const int blocks = std::min(resample_tile_blocks(t), max_blocks);
     return dispatch(stream, OpInfo{"resample_loss", 0.0, (double)N * H * W * (8.0 + 8.0 + 8.0 + 12.0 * C)}, [=](hipStream_t s) {
@@ -484,17 +525,17 @@ int mv3d_pixel_loss_strided(int64_t pixels, int ch, const void* a, int a_ld, con
     if (!a || !b || !loss_accum) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: null pointer");
     if (a_ld < ch || b_ld < ch || (grad && grad_ld < ch) || (mask && mask_ld < 1)) return fail(MV3D_E_INVAL, "mv3d_pixel_loss: pixel stride smaller than the channel count");
     PixelLossParams p = {pixels, ch, (const float*)a, a_ld, (const float*)b, b_ld, b_scale, (const float*)mask, mask_ld, kind, weight,
-                         (float*)loss_accum, (float*)grad, grad_ld};
+                         (float*)loss_accum, (float*)grad, grad_ld, next_loss_row()};
     const int64_t total = pixels * ch;
     const bool dense = a_ld == ch && b_ld == ch && (!grad || grad_ld == ch) && !mask && b_scale == 1.0f && (total & 3) == 0 &&
                        ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)grad)) & 15) == 0;
     if (dense) {
         const int64_t total4 = total >> 2;
-        // one workgroup per CU: every workgroup ends with an atomic on the single loss word, and those serialise
+        // one workgroup per CU
         const int blocks4 = (int)std::min<int64_t>(cdiv64(total4, 256 * 2), 256);
         return dispatch(stream, OpInfo{"pixel_loss", 0.0, (double)total * (grad ? 12.0 : 8.0)}, [=](hipStream_t s) {
             pixel_loss_dense_kernel<<<blocks4, 256, 0, s>>>(total4, pixels, (const float4*)a, (const float4*)b, kind, weight,
-                                                           (float*)loss_accum, (float4*)grad);
+                                                           (float*)loss_accum, (float4*)grad, p.loss_row);
             return launched("pixel_loss_dense_kernel");
         });
     }

@@ -258,12 +258,14 @@ class ConvNode(Node):
         us = 12.0 + 2.0 * geom.N * geom.Ho * geom.Wo * kh * kw * geom.C * geom.K / 120e6      # rough kernel time, microseconds
         ws_side = g.begin_side(us + 10.0, us if x.requires_grad else 0.0)
         old_cus = g.lib.set_wgrad_cus(self.wg_cus)
-        if self.transposed:
-            g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, ws_side, g.ws_bytes, g.stream)
-        else:
-            g.lib.conv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr,
-                               self.b.grad_ptr if self.b is not None else None, ws_side, g.ws_bytes, g.stream)
-        g.lib.set_wgrad_cus(old_cus)
+        try:
+            if self.transposed:
+                g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, ws_side, g.ws_bytes, g.stream)
+            else:
+                g.lib.conv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr,
+                                   self.b.grad_ptr if self.b is not None else None, ws_side, g.ws_bytes, g.stream)
+        finally:
+            g.lib.set_wgrad_cus(old_cus)      # process-global override: never leave it set behind a failed call
         g.end_side()
         self.w.has_grad = True
         if self.b is not None:
@@ -296,7 +298,8 @@ class LinearNode(Node):
             return
         _ensure_premasked(g, y)
         B, fin, fout = x.shape[0], x.C, y.C
-        if g._fusing and g.lib.fc_wgrad_adam_supported(B, fin, fout, x.ld, y.ld):
+        # the fused kernel reads x and dy with 16-byte loads: a channel slice at an odd offset takes fc_wgrad + adam_step_dev
+        if g._fusing and g.lib.fc_wgrad_adam_supported(B, fin, fout, x.ld, y.ld) and x.ptr % 16 == 0 and y.grad_ptr % 16 == 0:
             # Single-GPU step: the matrix gradient never goes to HBM -- ApplyAdam runs in the epilogue of the filter-gradient
             # kernel (mv3d_fc_wgrad_adam).  It rewrites the matrix, so it is recorded BEHIND the layer's data gradient (the
             # last reader of the old weights; the side stream forks after it); the bias gradient takes the ordinary path.
@@ -1069,6 +1072,7 @@ class Graph:
                 comm.reduce_scatter_sum_(self.grads, lo, n, cs)
                 a = lo + comm.rank * n
                 self._adam_range(a, a + n, cs)
+                self._slots_sharded = True      # this rank's Adam slots are now current on its own slices only
                 # the updated slices of a bucket whose parameters the next forward pass reads late (the fc matrices: 97 % of the
                 # bytes) are gathered AFTER every bucket has been reduced and, on the GPU, under the next step's encoder
                 use = self._bucket_first_use[self.grad_buckets.index((end, lo, hi))]
@@ -1132,10 +1136,34 @@ class Graph:
         self._settle()
         return OrderedDict((k, v.grad_value().detach().cpu().numpy().copy()) for k, v in self.variables.items() if v.has_grad)
 
+    def gather_optimizer_state(self):
+        """COLLECTIVE (every rank calls it): after sharded data-parallel steps a rank's Adam slots are current only on its own
+        1/world slice of every bucket; all-gather them (same lo / n layout as the parameters) so that any rank can write a
+        complete checkpoint.  No-op on one GPU and in 'allreduce' mode."""
+        self._settle()
+        if self.world_size <= 1 or not getattr(self, '_slots_sharded', False):
+            return
+        on_gpu = torch.device(self.device).type == 'cuda'
+        if on_gpu:
+            torch.cuda.synchronize(self.device)
+        cs = self._stream_ptr() if on_gpu else None
+        W = self.world_size
+        for _, lo, hi in self.grad_buckets:
+            if hi > lo:
+                n = (hi - lo) // W
+                self.comm.allgather_(self.adam_m, lo, n, cs)
+                self.comm.allgather_(self.adam_v, lo, n, cs)
+        if on_gpu:
+            torch.cuda.synchronize(self.device)
+        self._slots_sharded = False
+
     def state_dict(self):
         """TF-Saver-style names: <var>, <var>/Adam, <var>/Adam_1, beta1_power, beta2_power
         (train.py:70-71 saves GLOBAL_VARIABLES)."""
         self._settle()
+        if self.world_size > 1 and getattr(self, '_slots_sharded', False):
+            raise RuntimeError("sharded data-parallel step: this rank holds 1/%d of the Adam slots; call "
+                               "Graph.gather_optimizer_state() on EVERY rank before state_dict() / Saver.save()" % self.world_size)
         sd = OrderedDict()
         for k, v in self.variables.items():
             sd[k] = v.value().detach().cpu().clone()

@@ -30,30 +30,87 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
-def make_comm(rank, world, backend='rccl'):
+_CONTROL = {}
+
+
+def control_group():
+    """The gloo process group that carries the control plane (agreement flags, the RCCL id, barriers).  The default group when
+    it is gloo; otherwise (the caller initialised torch.distributed with nccl) an explicit gloo group, created once -- collective:
+    every rank must call it."""
+    import torch.distributed as dist
+    if 'g' not in _CONTROL:
+        _CONTROL['g'] = None if dist.get_backend() == 'gloo' else dist.new_group(backend='gloo')
+    return _CONTROL['g']
+
+
+def _agree(flag, group):
+    """True iff `flag` holds on every rank (MIN all-reduce on the control plane)."""
+    import torch.distributed as dist
+    ok = torch.tensor([1 if flag else 0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    return int(ok.item()) == 1
+
+
+def make_comm(rank, world, backend='rccl', fallback='nccl', _fault=None):
     """Communicator of the data-parallel step.  backend 'rccl': RCCL through the C ABI (csrc/comm.hip), the id travels over the
-    control-plane group (gloo) -- every rank must succeed, otherwise all ranks fall back together to 'nccl' = torch.distributed's
-    own RCCL binding; 'gloo': the control-plane group itself (CPU rehearsals).  torch.distributed must be initialised (gloo)."""
+    control-plane group (gloo); 'nccl': torch.distributed's own RCCL binding; 'gloo': the control-plane group itself (CPU
+    rehearsals).  torch.distributed must be initialised.
+
+    The 'rccl' route either succeeds on EVERY rank or every rank falls back together to `fallback`: the ranks agree on the
+    control plane BEFORE each blocking step, so an asymmetric failure never leaves one rank in a collective its peers do not enter --
+      1. MIN over ranks of "the library and an RCCL are loadable here";
+      2. rank 0 creates the id -- or fails -- and broadcasts the id or None;
+      3. every rank joins (ncclCommInitRank, itself a blocking collective) under a watchdog (MV3D_COMM_INIT_TIMEOUT seconds,
+         default 120): a rank whose peers never arrive gives up instead of waiting forever; MIN over ranks of "joined".
+    `_fault` = (rank, 'available' | 'id' | 'init') makes that step raise on that rank (tests/test_dist_cpu.py)."""
+    import sys
     import torch.distributed as dist
     if backend == 'rccl':
+        grp = control_group()
         comm, err = None, None
+
+        def faulty(step):
+            if _fault is not None and _fault[0] == rank and _fault[1] == step:
+                raise RuntimeError("injected failure at step %r on rank %d" % (step, rank))
+
         try:
-            comm = RcclComm(rank, world)
+            faulty('available')
+            from . import _lib
+            avail = bool(_lib.lib().comm_available())
         except Exception as e:          # noqa: BLE001 -- any failure must be agreed on by all ranks before anyone proceeds
-            err = e
-        ok = torch.tensor([1 if comm is not None else 0])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
+            avail, err = False, e
+        stage = 'available'
+        good = _agree(avail, grp)
+        if good:
+            stage = 'id'
+            ids = [None]
+            if rank == 0:
+                try:
+                    faulty('id')
+                    ids = [RcclComm.unique_id()]
+                except Exception as e:  # noqa: BLE001
+                    err = e
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0, group=grp)
+            good = ids[0] is not None
+        if good:
+            stage = 'init'
+            try:
+                faulty('init')
+                comm = RcclComm(rank, world, unique_id=ids[0], timeout=float(os.environ.get('MV3D_COMM_INIT_TIMEOUT', '120')))
+            except Exception as e:      # noqa: BLE001
+                err = e
+            good = _agree(comm is not None, grp)
+        if good:
             return comm
         if comm is not None:
             comm.close()
-        if rank == 0:
-            import sys
-            print("[mv3d] RCCL through the C ABI unavailable on some rank (%r): falling back to torch.distributed nccl" % (err,), file=sys.stderr)
-        backend = 'nccl'
+        print("[mv3d] rank %d: RCCL through the C ABI unavailable on some rank (step %r, local error %r): all ranks fall back to %s"
+              % (rank, stage, err, fallback), file=sys.stderr)
+        backend = fallback
     if backend == 'nccl':
         return TorchComm(dist.new_group(backend='nccl'))
-    return TorchComm(None)
+    return TorchComm(control_group())
 
 
 def bucket_views(flat, bucket_elems):
@@ -119,27 +176,60 @@ class TorchComm:
 
 
 class RcclComm:
-    """RCCL behind the C ABI (csrc/comm.hip).  The 128-byte id travels from rank 0 over the control-plane process group
-    (torch.distributed, gloo); every rank then joins on its own, already selected, device."""
+    """RCCL behind the C ABI (csrc/comm.hip).  The 128-byte id comes from rank 0 (`unique_id()`) over the control plane
+    (make_comm); every rank then joins on its own, already selected, device."""
 
-    def __init__(self, rank, world, control_group=None):
+    @staticmethod
+    def unique_id():
         import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        if not L.comm_available():
+            raise _lib.Mv3dError("no RCCL in this process (librccl.so not found)")
+        buf = C.create_string_buffer(128)
+        L.comm_unique_id(buf)
+        return buf.raw
+
+    def __init__(self, rank, world, control_group=None, unique_id=None, timeout=None):
+        import ctypes as C
+        import threading
         import torch.distributed as dist
         from . import _lib
         self.lib = _lib.lib()
         self.rank, self.world = rank, world
+        self._comm = None
         if not self.lib.comm_available():
             raise _lib.Mv3dError("no RCCL in this process (librccl.so not found)")
-        ids = [None]
-        if rank == 0:
-            buf = C.create_string_buffer(128)
-            self.lib.comm_unique_id(buf)
-            ids = [buf.raw]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=0, group=control_group)
-        self._id = C.create_string_buffer(ids[0], 128)
-        self._comm = C.c_void_p()
-        self.lib.comm_init(C.byref(self._comm), rank, world, self._id)
+        if unique_id is None:            # stand-alone use (world 1, tools): rank 0's id over the given control group
+            ids = [RcclComm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0, group=control_group)
+            unique_id = ids[0]
+        self._id = C.create_string_buffer(unique_id, 128)
+        comm = C.c_void_p()
+        box = {}
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def join():
+            try:
+                if dev is not None:
+                    torch.cuda.set_device(dev)          # the HIP device is per thread
+                self.lib.comm_init(C.byref(comm), rank, world, self._id)
+                box['ok'] = True
+            except Exception as e:      # noqa: BLE001
+                box['err'] = e
+
+        if timeout is None:
+            join()
+        else:                           # ncclCommInitRank blocks until every rank has arrived: give up after `timeout` seconds
+            t = threading.Thread(target=join, daemon=True)
+            t.start()
+            t.join(timeout)
+            if t.is_alive():
+                raise TimeoutError("ncclCommInitRank did not return within %.0f s (a peer never joined)" % timeout)
+        if 'err' in box:
+            raise box['err']
+        self._comm = comm
 
     def allreduce_sum_(self, buf, lo, n, stream):
         self.lib.comm_allreduce_sum(self._comm, buf.data_ptr() + 4 * lo, n, stream)

@@ -191,9 +191,11 @@ def main(argv=None):
             vc = float(model.forward(**val_data.next()))
             if rank == 0:
                 log.write(json.dumps({'itr': itr, 'val_loss': vc}) + '\n')
-        if itr % SAVE_INTERVAL == 0 and itr != 0 and rank == 0:
-            print('Saving model to' + conf['output_dir'])
-            saver.save(None, conf['output_dir'] + '/model' + str(itr))
+        if itr % SAVE_INTERVAL == 0 and itr != 0:
+            model.graph.gather_optimizer_state()        # collective: the sharded optimiser's slots, complete on every rank
+            if rank == 0:
+                print('Saving model to' + conf['output_dir'])
+                saver.save(None, conf['output_dir'] + '/model' + str(itr))
         t_iter.append(time.time() - t_startiter)
         if itr % 100 == 1 and rank == 0:
             torch.cuda.synchronize()
@@ -201,6 +203,7 @@ def main(argv=None):
             print('time per iteration: {0}'.format(avg_t_iter))
             print('expected for complete training: {0}h '.format(avg_t_iter / 3600 * conf['num_iterations']))
             log.flush()
+    model.graph.gather_optimizer_state()
     if rank == 0:
         print('Saving model.')
         saver.save(None, conf['output_dir'] + '/model')

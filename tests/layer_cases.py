@@ -82,6 +82,15 @@ MULTIOBJ_256_B32 = [
 MULTIOBJ_256_CONF = {'use_color': '', 'use_depth': 0.1, 'combination_image': '', 'gen_sep_images': '', 'fully_conv': '', 'image_size': 256}
 FC_MULTIOBJ = [(32, 2, 64, 2, 64), (32, 64, 64, 64, 64)]       # the angle MLP (a0, a1 / a2)
 
+# Kernel instances that try_hconv can dispatch but none of the configurations above does.
+#   cconv<3x3,256px,N32(,gmask)>: 3x3 stride-1 on >= 512 (16 x 16 tile, 32-filter) tasks -- the 16 x 16-tile instance of the
+#   3x3 pipelined kernel, whose data gradient keeps FOUR groups of saved-output loads in flight (with two, the
+#   mask of a group was overwritten before its stores left).
+EXTRA_KERNEL_CASES = [
+    (CONV, 64, 32, 32, 64, 64, 3, 1, 64, 64, True),       # 256 tiles x 2 filter blocks = 512 tasks
+    (CONV, 128, 16, 16, 128, 128, 3, 1, 128, 160, True),  # 128 tiles x 4 = 512, output into a wider buffer
+]
+
 FC_B64 = [  # B, in, out, x_ld, y_ld
     (64, 4096, 4096, 4096, 4160),     # fc1 (writes into the [fc1, a2] concat buffer)
     (64, 2, 64, 2, 64),               # a0

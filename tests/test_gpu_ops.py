@@ -294,7 +294,14 @@ def test_fused_resample_loss_matches_the_three_separate_ops(kind, n, h, c):
     L().warp_resample_loss(n, h, h, h, h, c, ds.data_ptr(), df.data_ptr(), 2, dt.data_ptr(), c, kind, wgt, None,
                            gen2.data_ptr(), None, 0, loss3.data_ptr(), stream())
     np.testing.assert_array_equal(host(gen), host(gen2))
-    assert host(loss3)[0] == host(loss)[0] or abs(host(loss3)[0] - host(loss)[0]) < 2e-6 * abs(host(loss)[0])
+    assert host(loss3)[0] == host(loss)[0]          # same kernel, same grid: the fixed-order loss sum gives the same bits
+    # and again, five times: the scalar loss is reproducible run to run (per-workgroup terms are summed in index order by the
+    # last workgroup to arrive, elem.hip loss_combine -- no float atomics race)
+    for _ in range(5):
+        lossr = torch.zeros(4, device='cuda')
+        L().warp_resample_loss(n, h, h, h, h, c, ds.data_ptr(), df.data_ptr(), 2, dt.data_ptr(), c, kind, wgt, None,
+                               gen2.data_ptr(), None, 0, lossr.data_ptr(), stream())
+        assert host(lossr)[0] == host(loss)[0]
 
 
 def test_zero_flow_is_exact_transpose():

@@ -99,3 +99,9 @@ def test_small_batch_cases_do_not_cover_the_benchmark():
              (LC.DECONV, 2, 64, 64, 32, 64, 5, 2, 32, 64, True)]
     big = _case_labels(LC.APPFLOW_B64, [])
     assert not {l for l in big if l.startswith('cconv<5x5,256px')} <= _case_labels(small, [])
+
+
+def test_extra_cases_reach_the_kernel_instances_they_are_there_for():
+    """LC.EXTRA_KERNEL_CASES exists for instances no shipped configuration dispatches: check that the cases really reach them."""
+    labels = _case_labels(LC.EXTRA_KERNEL_CASES, [])
+    assert 'cconv<3x3,256px,N32,gmask>' in labels and 'cconv<3x3,256px,N32>' in labels, sorted(labels)
