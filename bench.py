@@ -47,7 +47,7 @@ def is_split_bf16(label):
 
 # conv / deconv family: forward, data-gradient and filter-gradient kernels of conv2d_msra / deconv2d_msra
 # (tf_utils.py:70-98) plus the launches that only exist to serve them (mv3d_plan_profile_select pattern syntax)
-CONV_FAMILY = ('cconv*|cwgrad*|bconv*|wgrad_b3*|wgrad_tile*|hconv*|igemm*|smallc_*|thin_*|filtgrad*|reduce_slabs|transpose_filter')
+CONV_FAMILY = ('cconv*|cwgrad*|bconv*|wgrad_b3*|wgrad_tile*|hconv*|igemm*|smallc_*|thin_*|filtgrad*|reduce_slabs|grad_finalize*|transpose_filter')
 
 
 def in_conv_family(label):
@@ -230,7 +230,13 @@ def main():
         if world > 1:
             g.allreduce_grads()
         adam_events[0].record()
-        if fused:       # the fc matrices were updated inside their filter-gradient kernels: the rest in one launch
+        if fused and g._finalized_in_plan:
+            # the plan's last launch (grad_finalize_adam) summed the filter-gradient slabs and updated everything but the fc
+            # matrices (fused into their filter-gradient kernels) and their biases: those four bias vectors in one launch here
+            lo, hi = g._bias_span
+            g._adam_range(lo, hi, g._stream_ptr(), g._bias_skip)
+            g._adam_advance()
+        elif fused:     # the fc matrices were updated inside their filter-gradient kernels: the rest in one launch
             g._adam_range(0, g.flat_size, g._stream_ptr(), (len(g._skip_lo), g._skip_lo, g._skip_hi))
             g._adam_advance()
         else:
@@ -282,6 +288,8 @@ def main():
         torch.cuda.synchronize()
         collect(table)
         adam_params = g.flat_size - (sum(int(h) - int(l) for l, h in zip(g._skip_lo, g._skip_hi)) if bwd_plan is not g.plan_bwd else 0)
+        if bwd_plan is not g.plan_bwd and g._finalized_in_plan:
+            adam_params = sum(n.b.size for n in g._fused_nodes)
         table['adam'] = dict(launches=1, flops=0.0, bytes=28.0 * adam_params, ms=adam_collect())
     else:
         for _ in range(max(args.warmup - 1, 0)):

@@ -61,6 +61,10 @@ STATUS_FUNCS = {
     "mv3d_adam_step_dev": [_i64, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_i64), C.POINTER(_i64), _vp],
     "mv3d_adam_advance": [_vp, _vp],
     "mv3d_fc_wgrad_adam": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mv3d_grad_finalize_begin": [],
+    "mv3d_grad_finalize_add": [_vp, _i64],
+    "mv3d_grad_finalize_commit": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mv3d_grad_finalize_abort": [],
     "mv3d_comm_unique_id": [_vp],
     "mv3d_comm_init": [C.POINTER(_vp), _i, _i, _vp],
     "mv3d_comm_destroy": [_vp],
@@ -90,6 +94,7 @@ OTHER_FUNCS = {
     "mv3d_version": (C.c_char_p, []),
     "mv3d_last_error": (C.c_char_p, []),
     "mv3d_conv_workspace_bytes": (_sz, [_G]),
+    "mv3d_conv_wgrad_workspace_bytes": (_sz, [_G]),
     "mv3d_fc_workspace_bytes": (_sz, [_i, _i, _i]),
     "mv3d_crc32c": (C.c_uint32, [_vp, _sz]),
     "mv3d_set_diagnostics": (C.c_int, [_i]),
@@ -97,6 +102,7 @@ OTHER_FUNCS = {
     "mv3d_tfrecord_close": (None, [_vp]),
     "mv3d_filter_prepared_bytes": (_sz, [_G, _i]),
     "mv3d_filter_cache_table_bytes": (_sz, []),
+    "mv3d_grad_finalize_table_bytes": (_sz, []),
     "mv3d_plan_create": (_vp, []),
     "mv3d_plan_destroy": (None, [_vp]),
     "mv3d_plan_size": (_i, [_vp]),

@@ -39,6 +39,19 @@ inline int launched(const char* what) {
     return MV3D_OK;
 }
 
+// Deferred slab reductions (mv3d_grad_finalize_*, elem.hip): while a collection is open on this thread the filter-gradient entry
+// points hand their per-slab partial sums to finalize_push() instead of launching reduce_slabs_kernel per layer; nslab == 0
+// marks a gradient that is already final at `out` (a single slab written in place).
+struct FinSegHost { const float* part; int nslab; int64_t count; float* out; };
+bool finalize_collecting();
+void finalize_push(const float* part, int nslab, int64_t count, float* out);
+void finalize_open();
+}  // namespace mv3d
+#include <vector>
+namespace mv3d {
+const std::vector<FinSegHost>* finalize_peek();             // nullptr when no collection is open
+void finalize_take(std::vector<FinSegHost>* out);          // closes the collection (out may be null)
+
 // Diagnostics mask (dispatch rungs switched off): MV3D_DISABLE at load time, mv3d_set_diagnostics()
 // at run time.  One definition for all translation units (core.hip).
 int disabled_paths();

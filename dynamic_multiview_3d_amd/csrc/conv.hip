@@ -15,6 +15,7 @@
 // Tiles are staged global -> registers -> LDS (next tile's loads in flight during the MFMAs) and
 // multiplied with v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
 #include "conv_common.h"
+#include "reduce_common.h"
 #include <algorithm>
 
 namespace mv3d {
@@ -823,56 +824,6 @@ __global__ __launch_bounds__(256) void filtgrad_kernel(const FiltgradParams p) {
     }
 }
 
-// Sums the per-slab partial filters in a fixed order (deterministic).  256 threads = 16 element lanes x 16 slab
-// lanes: each thread adds every 16th slab with independent loads in flight, the 16 lanes of an element are combined
-// through LDS.  VEC=4: an element lane owns four consecutive floats (16-byte loads, 256 contiguous bytes per slab row
-// and wave quarter); VEC=1 is the scalar form for counts that are not a multiple of four and for the bias segment.
-template <int VEC>
-__device__ __forceinline__ void reduce_slabs_body(const float* __restrict__ part, int nslab, int64_t count,
-                                                  float* __restrict__ out, int blk, float (*s_sum)[16][17]) {
-    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int64_t i = ((int64_t)blk * 16 + e) * VEC;
-    float acc[8][VEC];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[u][v] = 0.f;
-    if (i < count) {
-        const float* p = part + (int64_t)sl * count + i;
-        const int64_t step = 16 * count;
-        int k = sl;
-        for (; k + 112 < nslab; k += 128, p += 8 * step) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if constexpr (VEC == 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(p + u * step);
-                    acc[u][0] += t.x; acc[u][1] += t.y; acc[u][2] += t.z; acc[u][3] += t.w;
-                } else {
-                    acc[u][0] += p[u * step];
-                }
-            }
-        }
-        for (; k < nslab; k += 16, p += step) {
-            if constexpr (VEC == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(p);
-                acc[0][0] += t.x; acc[0][1] += t.y; acc[0][2] += t.z; acc[0][3] += t.w;
-            } else {
-                acc[0][0] += p[0];
-            }
-        }
-    }
-#pragma unroll
-    for (int v = 0; v < VEC; ++v)
-        s_sum[v][sl][e] = ((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v])) + ((acc[4][v] + acc[5][v]) + (acc[6][v] + acc[7][v]));
-    __syncthreads();
-    if (sl < VEC && i < count) {                       // thread (sl = v, e) finishes component v of element lane e
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += s_sum[sl][j][e];
-        out[i + sl] = t;
-    }
-}
-
 template <int VEC>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ part, int nslab, int64_t count,
                                                           float* __restrict__ out, const float* __restrict__ part2,
@@ -880,8 +831,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     // two segments in one launch: the filter partials and (optionally) the bias partials
     __shared__ float s_sum[4][16][17];
     const int blk = blockIdx.x;
-    if (blk >= blocks1) reduce_slabs_body<1>(part2, nslab, count2, out2, blk - blocks1, s_sum);
-    else reduce_slabs_body<VEC>(part, nslab, count, out, blk, s_sum);
+    if (blk >= blocks1) reduce_slabs_body<1>(part2, nslab, count2, blk - blocks1, s_sum, [&](int64_t i, float t) { out2[i] = t; });
+    else reduce_slabs_body<VEC>(part, nslab, count, blk, s_sum, [&](int64_t i, float t) { out[i] = t; });
 }
 
 
@@ -1089,6 +1040,11 @@ static bool thin_filtgrad_plan(const mv3d_conv_geom* g, ThinFgParams& p, int* ns
 }
 
 static int dispatch_reduce(void* stream, const float* part, int nslab, int64_t fcount, float* df, const float* bpart, int K, float* db) {
+    if (finalize_collecting()) {          // one batched reduction (+ optimiser) at the end of the pass: mv3d_grad_finalize_commit
+        finalize_push(part, nslab, fcount, df);
+        if (db && bpart) finalize_push(bpart, nslab, K, db);
+        return MV3D_OK;
+    }
     const bool vec = fcount % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
     const int blocks1 = (int)cdiv64(fcount, vec ? 64 : 16);
     const int blocks2 = (db && bpart) ? cdiv(K, 16) : 0;
@@ -1516,6 +1472,7 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
             }
             int ns = 0;
             rc = wgrad_tile_launch_erased(g, img, feat, part, bpart, stream, who, &ns);
+            if (rc == MV3D_OK && ns == 1 && finalize_collecting()) { finalize_push(nullptr, 0, fcount, dfp); if (dbp) finalize_push(nullptr, 0, K, dbp); }
             if (rc != MV3D_OK || ns == 1) return rc;
             return dispatch_reduce(stream, part, ns, fcount, dfp, bpart, K, dbp);
         }
@@ -1561,6 +1518,7 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
         else { if (wide) filtgrad_kernel<1, 8><<<grid, 256, 0, s>>>(p); else filtgrad_kernel<1, 2><<<grid, 256, 0, s>>>(p); }
         return launched(who);
     });
+    if (rc == MV3D_OK && nslab == 1 && finalize_collecting()) { finalize_push(nullptr, 0, fcount, dfp); if (dbp) finalize_push(nullptr, 0, K, dbp); }
     if (rc != MV3D_OK || nslab == 1) return rc;
     return dispatch_reduce(stream, p.out, nslab, fcount, dfp, p.bias_out, K, dbp);
 }
@@ -1621,6 +1579,11 @@ int mv3d_filter_cache_bind(const mv3d_conv_geom* g, int op, const void* w, void*
 }
 
 int mv3d_set_wgrad_cus(int cus) { return set_wgrad_cus(cus); }
+
+size_t mv3d_conv_wgrad_workspace_bytes(const mv3d_conv_geom* g) {
+    if (!g || check_geom(g, "mv3d_conv_wgrad_workspace_bytes") != MV3D_OK) return 0;
+    return filtgrad_ws_bytes(g);
+}
 
 size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g) {
     if (!g || check_geom(g, "mv3d_conv_workspace_bytes") != MV3D_OK) return 0;

@@ -62,6 +62,17 @@ const char* intern_label(const char* fmt, ...) {
     std::lock_guard<std::mutex> lk(mu);
     return labels->insert(buf).first->c_str();
 }
+static thread_local std::vector<FinSegHost>* g_fin = nullptr;
+bool finalize_collecting() { return g_fin != nullptr; }
+void finalize_open() { if (!g_fin) g_fin = new std::vector<FinSegHost>(); }
+void finalize_push(const float* part, int nslab, int64_t count, float* out) { if (g_fin) g_fin->push_back(FinSegHost{part, nslab, count, out}); }
+const std::vector<FinSegHost>* finalize_peek() { return g_fin; }
+void finalize_take(std::vector<FinSegHost>* out) {
+    if (!g_fin) return;
+    if (out) out->swap(*g_fin);
+    delete g_fin;
+    g_fin = nullptr;
+}
 bool recording() { return g_rec != nullptr; }
 void record(std::function<int(hipStream_t)> fn, const OpInfo& info) { g_rec->ops.push_back(PlanOp{std::move(fn), info, 0.0, 0, true, g_side}); }
 }  // namespace mv3d

@@ -2,6 +2,8 @@
 // losses, fused TF-Adam, activation fwd/bwd, strided copies.  Built with -ffp-contract=off so the
 // fp32 expressions round exactly like the reference's unfused TF kernels (and the numpy oracle).
 #include "common.h"
+#include "reduce_common.h"
+#include <vector>
 #include <algorithm>
 #include <cstdlib>
 #include <atomic>
@@ -405,6 +407,71 @@ __global__ void adam_advance_kernel(float* st) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st[4] = st[4] * st[1]; st[5] = st[5] * st[2]; }      // beta_power *= beta, in fp32 like TF's update op
 }
 
+// ---------------------------------------------------------------- gradient finalisation: ONE launch at the end of the reverse pass
+// Every conv / deconv filter gradient leaves its kernel as per-slab partial sums; they used to be summed by one reduce_slabs
+// launch per layer (19 per step on AppearanceFlowModel) and the optimiser then re-read the sums.  Here a table of segments
+// {partials, slabs, count, position in the flat buffers} drives one launch: a workgroup sums its 64 elements over the slabs in
+// the order reduce_slabs_kernel uses (reduce_common.h: same bits) and either stores the gradient or applies TF's ApplyAdam to
+// that element right away (the arithmetic of adam_dev_kernel, operation for operation).  Segments with nslab == 0 are gradients
+// already final in the flat gradient buffer (biases of fc layers, the angle MLP): optimiser only.
+struct FinSeg {
+    const float* part; float* out;      // partials [nslab][count]; where the summed gradient goes (gradients-only mode)
+    int64_t off;                        // element offset of `out` in the flat gradient / parameter / slot buffers (optimiser mode)
+    int64_t count;
+    int nslab, vec, blk0, pad;
+};
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const FinSeg* __restrict__ segs, const int* __restrict__ seg_of_blk,
+                                                           const float* __restrict__ G, float* __restrict__ P, float* __restrict__ M,
+                                                           float* __restrict__ V, const float* __restrict__ st) {
+    __shared__ float s_sum[4][16][17];
+    const FinSeg sg = segs[seg_of_blk[blockIdx.x]];
+    const int blk = (int)blockIdx.x - sg.blk0;
+    float alpha = 0.f, omb1 = 0.f, omb2 = 0.f, eps = 0.f, gscale = 1.f;
+    if (ADAM) {
+        const float lr = st[0], b1 = st[1], b2 = st[2], b1p = st[4], b2p = st[5];
+        eps = st[3]; gscale = st[6];
+        alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+        omb1 = 1.0f - b1; omb2 = 1.0f - b2;
+    }
+    auto adam1 = [&](int64_t i, float g) {             // flat index i
+        const float gk = g * gscale;
+        float m = M[i], v = V[i], pp = P[i];
+        m += (gk - m) * omb1;
+        v += (gk * gk - v) * omb2;
+        pp -= (m * alpha) / (sqrtf(v) + eps);
+        P[i] = pp; M[i] = m; V[i] = v;
+    };
+    if (sg.nslab == 0) {
+        // final gradients: 1024 elements per workgroup, 16 bytes per lane (count is padded to a multiple of 4 by the host)
+        if (!ADAM) return;
+        const int64_t i4 = (int64_t)blk * 256 + threadIdx.x;
+        if (i4 * 4 >= sg.count) return;
+        const int64_t i = (sg.off >> 2) + i4;
+        float4 pp = reinterpret_cast<float4*>(P)[i], gg = reinterpret_cast<const float4*>(G)[i];
+        float4 mm = reinterpret_cast<float4*>(M)[i], vv = reinterpret_cast<float4*>(V)[i];
+        float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ge[k] * gscale;
+            me[k] += (gk - me[k]) * omb1;
+            ve[k] += (gk * gk - ve[k]) * omb2;
+            pe[k] -= (me[k] * alpha) / (sqrtf(ve[k]) + eps);
+        }
+        reinterpret_cast<float4*>(P)[i] = pp;
+        reinterpret_cast<float4*>(M)[i] = mm;
+        reinterpret_cast<float4*>(V)[i] = vv;
+        return;
+    }
+    auto fin = [&](int64_t i, float t) {
+        if (ADAM) adam1(sg.off + i, t);
+        else sg.out[i] = t;
+    };
+    if (sg.vec) reduce_slabs_body<4>(sg.part, sg.nslab, sg.count, blk, s_sum, fin);
+    else reduce_slabs_body<1>(sg.part, sg.nslab, sg.count, blk, s_sum, fin);
+}
+
 // ---------------------------------------------------------------- activations / copies
 __global__ __launch_bounds__(256) void act_fwd_kernel(int64_t rows, int ch, const float* x, int x_ld, float* y, int y_ld,
                                                      int act, float leak) {
@@ -644,6 +711,91 @@ int mv3d_group_sum(int64_t groups, int group, int ch, const void* src, int64_t s
     return dispatch(stream, OpInfo{"group_sum", 0.0, 4.0 * groups * ch * (group + 1)}, [=](hipStream_t s) {
         group_sum_kernel<<<grid_for(groups * ch), 256, 0, s>>>(groups, group, ch, (const float*)src, src_ld, (float*)dst, dst_ld);
         return launched("group_sum_kernel");
+    });
+}
+
+// ---- gradient finalisation (see grad_finalize_kernel) -------------------------------------------------------------------------
+int mv3d_grad_finalize_begin(void) {
+    if (finalize_collecting()) return fail(MV3D_E_INVAL, "mv3d_grad_finalize_begin: a collection is already open on this thread");
+    finalize_open();
+    return MV3D_OK;
+}
+int mv3d_grad_finalize_add(void* grad, int64_t count) {
+    if (!finalize_collecting()) return fail(MV3D_E_INVAL, "mv3d_grad_finalize_add: no open collection");
+    if (!grad || count <= 0 || ((uintptr_t)grad & 15)) return fail(MV3D_E_INVAL, "mv3d_grad_finalize_add: bad range (16-byte aligned, count > 0)");
+    finalize_push(nullptr, 0, count, (float*)grad);
+    return MV3D_OK;
+}
+int mv3d_grad_finalize_abort(void) { finalize_take(nullptr); return MV3D_OK; }
+
+static int fin_blocks(const FinSegHost& h) {
+    if (h.nslab == 0) return (int)cdiv64(cdiv64(h.count, 4), 256);
+    const bool vec = h.count % 4 == 0 && ((uintptr_t)h.part & 15) == 0;
+    return (int)cdiv64(h.count, vec ? 64 : 16);
+}
+size_t mv3d_grad_finalize_table_bytes(void) {
+    const std::vector<FinSegHost>* v = finalize_peek();
+    if (!v) return 0;
+    size_t blocks = 0;
+    for (const FinSegHost& h : *v) blocks += fin_blocks(h);
+    return ((v->size() * sizeof(FinSeg) + 255) & ~(size_t)255) + blocks * sizeof(int);
+}
+int mv3d_grad_finalize_commit(void* table, size_t table_bytes, void* grads, void* params, void* adam_m, void* adam_v,
+                              const void* adam_state, void* stream) {
+    if (!finalize_collecting()) return fail(MV3D_E_INVAL, "mv3d_grad_finalize_commit: no open collection");
+    const size_t need = mv3d_grad_finalize_table_bytes();
+    std::vector<FinSegHost> segs;
+    finalize_take(&segs);
+    const bool adam = adam_state != nullptr;
+    if (adam && (!grads || !params || !adam_m || !adam_v || (((uintptr_t)grads | (uintptr_t)params | (uintptr_t)adam_m | (uintptr_t)adam_v) & 15)))
+        return fail(MV3D_E_INVAL, "mv3d_grad_finalize_commit: the optimiser needs the four flat buffers (16-byte aligned)");
+    // one segment per gradient: a range named 'already final' (by the caller, or by a single-slab filter gradient written in place)
+    // that a slab segment also produces is the slab segment's, and a range named twice counts once
+    std::vector<FinSegHost> keep;
+    for (size_t a = 0; a < segs.size(); ++a) {
+        const FinSegHost& h = segs[a];
+        bool dup = false;
+        for (size_t b = 0; b < segs.size(); ++b) {
+            if (b == a || segs[b].out != h.out) continue;
+            if (h.nslab == 0 && (segs[b].nslab > 0 || b < a)) dup = true;
+            if (h.nslab > 0 && segs[b].nslab > 0 && b < a) return fail(MV3D_E_INVAL, "mv3d_grad_finalize_commit: two filter gradients write the same range");
+        }
+        if (!dup && (adam || h.nslab > 0)) keep.push_back(h);
+    }
+    if (keep.empty()) return MV3D_OK;
+    const bool dry = !table && recording();      // a plan recorded without a device (host-logic tests): never runs, nothing to upload
+    if (!dry && (!table || table_bytes < need || ((uintptr_t)table & 15))) return fail(MV3D_E_WORKSPACE, "mv3d_grad_finalize_commit: table %zu < %zu bytes", table_bytes, need);
+    std::vector<FinSeg> dev(keep.size());
+    std::vector<int> seg_of;
+    double bytes = 0.0;
+    for (size_t j = 0; j < keep.size(); ++j) {
+        const FinSegHost& h = keep[j];
+        FinSeg& d = dev[j];
+        d.part = h.part; d.out = h.out; d.count = h.count; d.nslab = h.nslab; d.pad = 0;
+        d.vec = h.nslab > 0 && h.count % 4 == 0 && ((uintptr_t)h.part & 15) == 0;
+        d.off = 0;
+        if (adam) {
+            const int64_t off = h.out - (float*)grads;
+            if (off < 0 || (h.nslab == 0 && (off & 3))) return fail(MV3D_E_INVAL, "mv3d_grad_finalize_commit: segment %zu is not inside the flat gradient buffer", j);
+            d.off = off;
+        }
+        d.blk0 = (int)seg_of.size();
+        const int nb = fin_blocks(h);
+        seg_of.insert(seg_of.end(), nb, (int)j);
+        bytes += 4.0 * h.count * (h.nslab + (adam ? 6 : 1));
+    }
+    const size_t seg_bytes = (dev.size() * sizeof(FinSeg) + 255) & ~(size_t)255;
+    // the table is written NOW (record time): a recorded plan replays the launch below against it
+    if (!dry && (hipMemcpy(table, dev.data(), dev.size() * sizeof(FinSeg), hipMemcpyHostToDevice) != hipSuccess ||
+                 hipMemcpy((char*)table + seg_bytes, seg_of.data(), seg_of.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
+        return fail(MV3D_E_HIP, "mv3d_grad_finalize_commit: table upload failed");
+    const FinSeg* dsegs = (const FinSeg*)table;
+    const int* dmap = (const int*)((char*)table + seg_bytes);
+    const int blocks = (int)seg_of.size();
+    return dispatch(stream, OpInfo{adam ? "grad_finalize_adam" : "grad_finalize", 0.0, bytes}, [=](hipStream_t s) {
+        if (adam) grad_finalize_kernel<true><<<blocks, 256, 0, s>>>(dsegs, dmap, (const float*)grads, (float*)params, (float*)adam_m, (float*)adam_v, (const float*)adam_state);
+        else grad_finalize_kernel<false><<<blocks, 256, 0, s>>>(dsegs, dmap, nullptr, nullptr, nullptr, nullptr, nullptr);
+        return launched("grad_finalize_kernel");
     });
 }
 

@@ -241,6 +241,13 @@ class ConvNode(Node):
         finally:
             g.lib.set_wgrad_cus(old)
 
+    def wgrad_partial_bytes(self, g):
+        old = g.lib.set_wgrad_cus(self.wg_cus)
+        try:
+            return int(g.lib.conv_wgrad_workspace_bytes(C.byref(self.geom())))
+        finally:
+            g.lib.set_wgrad_cus(old)
+
     def forward(self, g):
         geom = self.geom()
         epi = _epi(self.b.ptr if self.b is not None else None, self.act, self.leak)
@@ -257,13 +264,18 @@ class ConvNode(Node):
         kh, kw = self.k[0], self.k[1]
         us = 12.0 + 2.0 * geom.N * geom.Ho * geom.Wo * kh * kw * geom.C * geom.K / 120e6      # rough kernel time, microseconds
         ws_side = g.begin_side(us + 10.0, us if x.requires_grad else 0.0)
+        ws_len = g.ws_bytes
+        if g._finalizing:
+            # mv3d_grad_finalize_*: the per-slab partial sums stay in THIS layer's region of the arena until the one batched
+            # reduction (+ optimiser) at the end of the pass has read them
+            ws_side, ws_len = g._part_arena.data_ptr() + self._part_off, self._part_bytes
         old_cus = g.lib.set_wgrad_cus(self.wg_cus)
         try:
             if self.transposed:
-                g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, ws_side, g.ws_bytes, g.stream)
+                g.lib.deconv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr, ws_side, ws_len, g.stream)
             else:
                 g.lib.conv2d_wgrad(C.byref(geom), x.ptr, y.grad_ptr, self.w.grad_ptr,
-                                   self.b.grad_ptr if self.b is not None else None, ws_side, g.ws_bytes, g.stream)
+                                   self.b.grad_ptr if self.b is not None else None, ws_side, ws_len, g.stream)
         finally:
             g.lib.set_wgrad_cus(old_cus)      # process-global override: never leave it set behind a failed call
         g.end_side()
@@ -496,6 +508,13 @@ class Graph:
         self.overlap_adam = os.environ.get('MV3D_OVERLAP_ADAM', '1') != '0'
         self.fuse_fc_adam = os.environ.get('MV3D_FUSE_FC_ADAM', '1') != '0'      # single-GPU step: Adam of the fc matrices inside their filter-gradient kernels
         self._fusing = False
+        # single-GPU step: the slab reductions of all conv filter gradients and the optimiser of everything that is not a fused fc
+        # matrix in ONE launch at the end of the reverse pass (mv3d_grad_finalize_*) instead of one reduction per layer + Adam
+        self.fuse_finalize = os.environ.get('MV3D_FUSE_FINALIZE', '1') != '0'
+        self.finalize_chunk_bytes = int(float(os.environ.get('MV3D_FINALIZE_CHUNK_MB', '48')) * 1e6)
+        self._finalizing = False
+        self._finalized_in_plan = False
+        self._part_arena = self._fin_table = None
         self._fused_vars = []
         # The fused fc optimiser (4 x 400 MB of HBM streaming) is not joined at the end of the step: it keeps running on its side
         # stream under the NEXT step's encoder, and the forward pass waits for it in front of the first launch that touches an fc
@@ -762,12 +781,33 @@ class Graph:
             self._clk_main = self._clk_side = 0.0
             self._side_rr = 0
             plan = lib.plan_create()
+            on_gpu = torch.device(self.device).type == 'cuda'
+            self._finalized_in_plan = False
+            if self.fuse_finalize:
+                # every conv layer gets its own region for its per-slab partial filters (they live until the end of the pass)
+                off = 0
+                for n in self.nodes:
+                    if isinstance(n, ConvNode):
+                        n._part_off, n._part_bytes = off, n.wgrad_partial_bytes(self)
+                        off += -(-n._part_bytes // 256) * 256
+                self._part_arena = torch.empty(max(off // 4, 4), dtype=torch.float32, device=self.device)
+                lib.grad_finalize_begin()
+                self._finalizing = True
+                self._fin_pending, self._fin_vars, self._fin_done, self._fin_tables = 0, [], set(), []
             lib.plan_begin(plan)
             self._fusing = True
             self._deferred = []
             try:
                 for n in reversed(self.nodes):
                     n.backward(self)
+                    if self._finalizing and isinstance(n, ConvNode) and n.w.has_grad:
+                        # the reduction (+ optimiser) of what has piled up goes out as soon as it is worth a launch: it then runs
+                        # beside the rest of the pass instead of in its tail
+                        self._fin_pending += n._part_bytes
+                        self._fin_vars += [n.w] + ([n.b] if n.b is not None else [])
+                        if self._fin_pending >= self.finalize_chunk_bytes:
+                            self._finalize_commit()
+                            lib.grad_finalize_begin()
                     for d in self._deferred:
                         d[0] -= 1
                     for d in [d for d in self._deferred if d[0] < 0]:
@@ -776,8 +816,22 @@ class Graph:
                 for d in self._deferred:
                     d[1]()
                 self._deferred = []
+                if self._finalizing and self._fused_vars:
+                    # everything else the optimiser owns: gradients that are already final in the flat buffer (the angle MLP, conv
+                    # layers whose filter gradient is a single slab); the fused fc matrices and their biases are updated on the
+                    # fused kernels' own stream (run_backward_fused).  Ranges a slab segment produces are dropped by the library.
+                    fused = {id(v) for v in self._fused_vars} | {id(n.b) for n in self._fused_nodes}
+                    for v in self.variables.values():
+                        if v.has_grad and id(v) not in fused and id(v) not in self._fin_done:
+                            lib.grad_finalize_add(v.grad_ptr, -(-v.size // 4) * 4)
+                    self._finalize_commit()
+                    self._finalizing = False
+                    self._finalized_in_plan = True
             finally:
                 self._fusing = False
+                if self._finalizing:
+                    lib.grad_finalize_abort()
+                    self._finalizing = False
                 lib.plan_end()
             if self._fused_vars:
                 self.plan_bwd_fused = plan
@@ -809,6 +863,23 @@ class Graph:
                 lib.plan_destroy(plan)
         self.upload_adam_state()
         return self
+
+    def _finalize_commit(self):
+        """Close the open mv3d_grad_finalize collection: one launch on the filter-gradient stream that sums the collected layers'
+        slabs and applies their optimiser update (recorded into the plan being recorded)."""
+        lib = self.lib
+        on_gpu = torch.device(self.device).type == 'cuda'
+        tb = int(lib.grad_finalize_table_bytes())
+        table = torch.empty(max(tb, 16), dtype=torch.uint8, device=self.device) if on_gpu else None
+        self._fin_tables.append(table)
+        self.begin_side(20.0, 0.0)
+        try:
+            lib.grad_finalize_commit(table.data_ptr() if on_gpu else None, tb, self.grads.data_ptr(), self.params.data_ptr(),
+                                     self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.adam_state.data_ptr(), self.stream)
+        finally:
+            self.end_side()
+        self._fin_done |= {id(v) for v in self._fin_vars}
+        self._fin_pending, self._fin_vars = 0, []
 
     def _bind_prepared_filters(self):
         """Weights only change in apply_adam(), so each conv filter is converted to the kernels' operand format
@@ -992,7 +1063,8 @@ class Graph:
             self._fc_event.record(fcq)
             self._fc_pending = True
             self._pending_idx = self._fwd_wait_idx
-        self._adam_range(0, self.flat_size, st, (len(self._skip_lo), self._skip_lo, self._skip_hi))
+        if not self._finalized_in_plan:          # otherwise the plan's last launch (grad_finalize_adam) was the optimiser of everything else
+            self._adam_range(0, self.flat_size, st, (len(self._skip_lo), self._skip_lo, self._skip_hi))
         self._adam_advance(st, both=False)
 
     def run_backward_with_adam(self):

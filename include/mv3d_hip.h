@@ -111,6 +111,9 @@ int mv3d_deconv2d_wgrad(const mv3d_conv_geom* g, const void* x, const void* dy, 
                         void* workspace, size_t workspace_bytes, void* stream);
 /* bytes of scratch the six calls above may need for this geometry (max over them) */
 size_t mv3d_conv_workspace_bytes(const mv3d_conv_geom* g);
+/* the part of it the filter-gradient call of this geometry needs (its per-slab partial sums): what a caller that gives every
+ * layer its own workspace (mv3d_grad_finalize_*) has to reserve per layer */
+size_t mv3d_conv_wgrad_workspace_bytes(const mv3d_conv_geom* g);
 
 /* ---- prepared filters (optional) -------------------------------------------------------------
  * The matrix-core convolution kernels read the filter split into bf16 hi/lo parts in MFMA fragment order.
@@ -214,6 +217,27 @@ int mv3d_adam_advance(void* adam_state, void* stream);
 int mv3d_fc_wgrad_adam(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* M, void* adam_m, void* adam_v,
                        void* db, const void* adam_state, void* stream);
 int mv3d_fc_wgrad_adam_supported(int B, int in, int out, int x_ld, int dy_ld);
+
+/* ---- gradient finalisation: the slab reductions of ALL filter gradients (+ their optimiser update) in one launch ------------
+ * Replaces, on the recorded single-GPU step, the per-layer partial-filter reductions behind tf.gradients' Conv2DBackpropFilter
+ * ops and the tf.train.AdamOptimizer ApplyAdam ops of every variable that is not an fc matrix (appearance_flow_model.py:77).
+ * Between mv3d_grad_finalize_begin() and _commit() on this thread the filter-gradient entry points (mv3d_conv2d_wgrad,
+ * mv3d_deconv2d_wgrad) leave their per-slab partial sums in the workspace they were given -- which the caller must then keep
+ * untouched until the committed launch has run, i.e. one workspace per layer -- and record a segment instead of launching a
+ * reduction.  mv3d_grad_finalize_add names a gradient range that is already final (fc biases, tiny fc layers) so that the
+ * optimiser covers it too.  _table_bytes: device bytes the segment table needs for what has been collected so far.
+ * _commit closes the collection, uploads the table (synchronously, at call / record time) and dispatches ONE launch that sums
+ * every segment's slabs in the fixed order of the per-layer reduction (same bits) and
+ *   adam_state == NULL: stores the gradients where the wgrad calls were told to (grads/params/adam_m/adam_v ignored);
+ *   adam_state != NULL: applies ApplyAdam to each element instead (mv3d_adam_step_dev's arithmetic, same bits); every
+ *                       segment must lie inside the flat buffer `grads`, whose layout params / adam_m / adam_v share.
+ * _abort drops an open collection.  (table may be NULL only while recording a plan without a device, which can never run.) */
+int mv3d_grad_finalize_begin(void);
+int mv3d_grad_finalize_add(void* grad, int64_t count);
+size_t mv3d_grad_finalize_table_bytes(void);
+int mv3d_grad_finalize_commit(void* table, size_t table_bytes, void* grads, void* params, void* adam_m, void* adam_v,
+                              const void* adam_state, void* stream);
+int mv3d_grad_finalize_abort(void);
 
 /* ---- data-parallel exchange: RCCL over xGMI behind the ABI (one process per GPU) -----------------------------------------
  * The reference trains on one device (multi_view_model/train.py:21,35); the batch shards over ranks and the flat fp32 gradient

@@ -341,3 +341,80 @@ def test_model_step_at_benchmark_batch():
     assert set(got) == set(grads)
     worst = max(_rel(got[k], grads[k]) for k in grads)
     assert worst < 1e-3, worst
+
+
+def test_grad_finalize_equals_per_layer_reduction_and_adam():
+    """mv3d_grad_finalize_*: three filter gradients (tiled MFMA kernel, transposed 3x3, thin 3-channel kernel) collected and
+    finished by ONE launch -- gradients-only mode bit-identical to the per-layer reduce_slabs launches, optimiser mode
+    bit-identical to those followed by mv3d_adam_step_dev over the flat buffer (parameters and both slots), with a plain
+    (already final) range in the middle of the buffer covered too."""
+    rng = np.random.default_rng(11)
+    lib = L()
+    cases = [(LC.CONV, 8, 32, 32, 32, 64, 5, 1), (LC.DECONV, 8, 16, 16, 64, 128, 3, 2), (LC.CONV, 8, 64, 64, 3, 32, 5, 2)]
+    layers, off = [], 0
+    for kind, n, h, w, c, k, ksz, s in cases:
+        g = _lib.conv_geom(n, h, w, c, k, ksz, ksz, s, s)
+        img = dev(rng.standard_normal((n, h, w, c)).astype(np.float32))
+        feat = dev(rng.standard_normal((n, g.Ho, g.Wo, k)).astype(np.float32))
+        wn = ksz * ksz * c * k
+        lay = dict(kind=kind, g=g, img=img, feat=feat, wn=wn, k=k, w_off=off)
+        off += -(-wn // 64) * 64
+        if kind == LC.CONV:
+            lay['b_off'] = off
+            off += -(-k // 64) * 64
+        layers.append(lay)
+    plain_off, plain_n = off, 192
+    off += 256
+    flat = off
+
+    def wgrads(grads, ws_of):
+        for i, lay in enumerate(layers):
+            ws, wsb = ws_of(i, lay)
+            gw = grads.data_ptr() + 4 * lay['w_off']
+            if lay['kind'] == LC.CONV:
+                lib.conv2d_wgrad(C.byref(lay['g']), lay['img'].data_ptr(), lay['feat'].data_ptr(), gw, grads.data_ptr() + 4 * lay['b_off'], ws, wsb, stream())
+            else:
+                lib.deconv2d_wgrad(C.byref(lay['g']), lay['feat'].data_ptr(), lay['img'].data_ptr(), gw, ws, wsb, stream())
+
+    plain = rng.standard_normal(plain_n).astype(np.float32)
+    ref = torch.zeros(flat, device='cuda')
+    ref[plain_off:plain_off + plain_n] = dev(plain)
+    shared = [conv_ws(lay['g']) for lay in layers]
+    wgrads(ref, lambda i, lay: (shared[i].ptr, shared[i].bytes))
+    torch.cuda.synchronize()
+    assert float(ref.abs().sum()) > 0
+
+    own = [Ws(max(int(lib.conv_wgrad_workspace_bytes(C.byref(lay['g']))), 16)) for lay in layers]
+    assert sum(int(lib.conv_wgrad_workspace_bytes(C.byref(lay['g']))) > 0 for lay in layers) >= 2      # the case really has slabs
+    # gradients only
+    got = torch.zeros(flat, device='cuda')
+    got[plain_off:plain_off + plain_n] = dev(plain)
+    lib.grad_finalize_begin()
+    wgrads(got, lambda i, lay: (own[i].ptr, own[i].bytes))
+    tb = int(lib.grad_finalize_table_bytes())
+    table = torch.empty(tb, dtype=torch.uint8, device='cuda')
+    lib.grad_finalize_commit(table.data_ptr(), tb, None, None, None, None, None, stream())
+    np.testing.assert_array_equal(host(got), host(ref))
+    # with the optimiser: two steps with a changing bias correction
+    state = np.array([1e-3, 0.9, 0.999, 1e-8, 0.9, 0.999, 1.0, 0.0], np.float32)
+    p0 = rng.standard_normal(flat).astype(np.float32)
+    pa, ma, va, sa = dev(p0), torch.zeros(flat, device='cuda'), torch.zeros(flat, device='cuda'), dev(state)
+    pb, mb, vb, sb = dev(p0), torch.zeros(flat, device='cuda'), torch.zeros(flat, device='cuda'), dev(state)
+    for step in range(2):
+        lib.adam_step_dev(flat, pa.data_ptr(), ref.data_ptr(), ma.data_ptr(), va.data_ptr(), sa.data_ptr(), 0, None, None, stream())
+        lib.adam_advance(sa.data_ptr(), stream())
+        gbuf = torch.zeros(flat, device='cuda')
+        gbuf[plain_off:plain_off + plain_n] = dev(plain)
+        lib.grad_finalize_begin()
+        wgrads(gbuf, lambda i, lay: (own[i].ptr, own[i].bytes))
+        lib.grad_finalize_add(gbuf.data_ptr() + 4 * plain_off, plain_n)
+        tb = int(lib.grad_finalize_table_bytes())
+        table = torch.empty(tb, dtype=torch.uint8, device='cuda')
+        lib.grad_finalize_commit(table.data_ptr(), tb, gbuf.data_ptr(), pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), sb.data_ptr(), stream())
+        lib.adam_advance(sb.data_ptr(), stream())
+        torch.cuda.synchronize()
+    # the reference optimiser ran over the whole flat buffer (zero gradients in the padding move nothing); compare everywhere
+    np.testing.assert_array_equal(host(ma), host(mb))
+    np.testing.assert_array_equal(host(va), host(vb))
+    np.testing.assert_array_equal(host(pa), host(pb))
+    assert np.abs(host(pb) - p0).max() > 0

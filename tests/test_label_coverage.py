@@ -27,6 +27,7 @@ ELEMENTWISE = {
     'bconv_split_all': 'tests/test_gpu_layers.py::test_model_step_at_benchmark_batch',     # the bound-filter conversion
     'fc_wgrad_adam_b3': 'tests/test_gpu_layers.py::test_fused_fc_wgrad_adam_equals_wgrad_then_adam',
     'adam': 'tests/test_gpu_ops.py::test_adam_bit_exact_vs_oracle',
+    'grad_finalize_adam': 'tests/test_gpu_layers.py::test_fused_step_equals_unfused_step',     # == reduce_slabs per layer + adam, bit for bit
     'adam_advance': 'tests/test_gpu_layers.py::test_fused_fc_wgrad_adam_equals_wgrad_then_adam',
 }
 
