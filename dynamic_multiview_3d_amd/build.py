@@ -15,6 +15,7 @@ UNITS = {
     "hconv.hip": [],
     "bconv.hip": [],
     "cconv.hip": (["-DCC_TAP_STAMPS"] if os.environ.get("MV3D_CC_TAP_STAMPS") else []),
+    "sconv.hip": [],
     "wgrad_tile.hip": [],
     "fc.hip": [],
     "elem.hip": ["-ffp-contract=off"],

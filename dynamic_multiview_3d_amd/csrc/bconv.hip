@@ -812,6 +812,31 @@ int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int M
 }
 
 
+// The prepared (fragment-ordered, split) copy of p's filter for kernels outside this file (sconv.hip): the bound copy of the
+// filter cache, or -- for an unbound filter -- a copy split into `ws` by a launch dispatched here.  Returns null with *rc set
+// when neither is possible (*rc = 1: the caller should fall back to another kernel).
+const uint4* bconv_get_filter(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, int* ntiles_out, int* rc) {
+    const int nph = p.so_h * p.so_w;
+    const int ntaps = p.tap_begin[nph];
+    const int chunks = cdiv(p.Ka, 32), ntiles = cdiv(p.Cc, 32);
+    int cached_tiles = 0;
+    const void* cached = bconv_cache_lookup(p, &cached_tiles);
+    if (cached && cached_tiles >= ntiles) { *ntiles_out = cached_tiles; *rc = MV3D_OK; return reinterpret_cast<const uint4*>(cached); }
+    const size_t need = bconv_filter_bytes(p, 1);
+    if (!ws || ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 15)) { *rc = 1; return nullptr; }
+    uint4* wf = reinterpret_cast<uint4*>(ws);
+    const int64_t threads = (int64_t)ntaps * chunks * ntiles * 2 * 64;
+    const int blocks = (int)cdiv64(threads, 256);
+    const IgemmParams pc = p;
+    *rc = dispatch(stream, OpInfo{"bconv_split_filter", 0.0, 2.0 * (double)ntaps * p.Ka * p.Cc * 4.0}, [=](hipStream_t s) {
+        bconv_split_filter_kernel<<<blocks, 256, 0, s>>>(pc, wf, ntaps, chunks, ntiles);
+        return launched("bconv_split_filter_kernel");
+    });
+    if (*rc != MV3D_OK) return nullptr;
+    *ntiles_out = ntiles;
+    return wf;
+}
+
 // ---- prepared-filter cache ------------------------------------------------------------------------
 // A caller that knows a set of filters stays constant over several convolution calls (a training step:
 // every filter is used by the forward pass and again, in the other orientation, by the backward-data pass)

@@ -74,6 +74,11 @@ void bconv_set_rows(HconvExtra* x, int stride_h = 1);
 int launch_bconv(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid,
                  void* wfrag, void* stream, const char* name, const char* who, double flops, double bytes);
 
+const uint4* bconv_get_filter(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, int* ntiles_out, int* rc);
+// sconv.hip: small-image convolution (8 x 8 / 4 x 4 phase grids) with the reduction split inside the workgroup -- no split-K
+// partials, no epilogue launch; returns 1 when the problem is not one of its
+int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes);
+
 // cconv.hip: software-pipelined split-bf16 convolution (one persistent 8-wave workgroup per CU, LDS-DMA halo staging) for
 // single-phase stride-1 5x5 / 3x3 problems on images of at least 16 x 16 pixels
 bool cconv_eligible(const IgemmParams& p, int* kw_out, bool* rev_out);

@@ -517,6 +517,10 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
         const int ipx = Hp * Wp;
         const bool pow2 = (ipx & (ipx - 1)) == 0 && (Wp & (Wp - 1)) == 0;
         if (ipx <= 64 && ipx >= 16 && pow2 && Wp >= 4 && !(disabled_paths() & 1024)) {
+            if (b3 && !(disabled_paths() & 16777216)) {      // reduction split inside the workgroup: one launch (sconv.hip)
+                const int rc = try_sconv(p, ws, ws_bytes, stream, who, flops, bytes);
+                if (rc != 1) return rc;
+            }
             HconvExtra x = {};
             x.G = 128 / ipx; x.TH = Hp; x.TW = Wp; x.tiles_h = 1; x.tiles_w = 1;
             x.tw_shift = 0; while ((1 << x.tw_shift) < Wp) ++x.tw_shift;

@@ -1,0 +1,270 @@
+// Small-image split-bf16 convolution: the 8 x 8 and 4 x 4 layers around the bottleneck (e3 .. e4_0, d4 .. d3 of
+// appearance_flow_model.py:93-97,111-114; conv2d_msra / deconv2d_msra forward and data gradient in every direction and stride).
+//
+// At batch 64 these layers are GEMMs with 1 k .. 4 k rows, 64 .. 256 columns and a reduction of 576 .. 2304: too few rows to fill
+// the chip with (pixel tile x filter tile) workgroups that each walk the whole reduction chunk by chunk, which is why the generic
+// kernel (bconv.hip) splits the channel chunks over workgroups and a second launch (igemm_splitk_epilogue) sums the partial
+// outputs -- 28 launches per step whose cost is the launch chain, not the arithmetic.  Here the reduction is split INSIDE the
+// workgroup instead:
+//   * a workgroup owns 32 pixels of the output's phase grid (two 4 x 4 images, or four rows of an 8 x 8 image) x 32 filters;
+//   * the input halo of those pixels is staged ONCE, for ALL channels (<= 150 KiB: 8-channel units of bf16 hi | lo, 32 bytes
+//     each, in place of the 32 bytes of fp32 they came from; pixel records padded by 32 bytes so that the 32 pixels of an
+//     A-fragment read fall on different banks), one barrier;
+//   * the (tap, 16-channel) steps of the reduction are dealt round-robin to the four waves; a wave streams its filter
+//     fragments from the prepared filter (bconv.hip: one coalesced 1 KiB line group per load) through an 8-deep register ring,
+//     reads its A fragments from the planes and accumulates a partial 32 x 32 tile per output phase;
+//   * the four partial tiles meet in LDS and are added in a fixed order (wave 0 + 1 + 2 + 3: reproducible), then bias,
+//     activation and the activation-gradient mask are applied and the tile is stored -- no partial sums in HBM, no second launch.
+// Stride-2 transposed convolutions (and the data gradient of stride-2 convolutions) are four output phases with their own tap
+// sets: grid.z is the phase, a workgroup stages the (small) halo and walks its phase's taps only, so the accumulator index is a
+// constant everywhere (one kernel with the phase selected per step by a branch kept the tile in flight through copies and made
+// hipcc wait for the filter ring at every join).
+//
+// The step loop is straight-line code (SC_MAXSTEPS steps, left early): hipcc's vmcnt bookkeeping is exact inside a basic-block
+// chain but conservative across a loop's back edge, where it drained the filter ring every R steps (one L2 round trip each
+// time).  Inline-asm loads with hand-counted waits were tried and dropped: hipcc copied ring registers whose loads were still
+// in flight at the branches around the waits (cdna_hip_programming.md 5.7, item 1).
+#include "conv_common.h"
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+namespace mv3d {
+
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sbf16x4 __attribute__((ext_vector_type(4)));
+constexpr int SC_MAXSTEPS = 48;      // reduction steps per wave the straight-line loop covers (9 taps x 320 channels / 16 / 4 = 45)
+
+struct SconvParams {
+    int TH;                 // phase-grid rows of one image slot covered by a tile
+    int G;                  // image slots per tile (2: 4 x 4 phase grids, 1 otherwise)
+    int tiles_h;            // row tiles per image
+    int tw_shift;           // log2(phase-grid width)
+    int slot_shift;         // log2(pixels per image slot) = log2(TH * Wp)
+    int HRi, HC, PS;        // halo rows per slot, halo columns, bytes per halo pixel record (4 * Ka + 32)
+    int dh_min, dw_min;
+    int nk16;               // Ka / 16: reduction steps per tap
+    unsigned inv_nk16;      // ceil(2^32 / nk16)
+    int nsteps;             // taps * nk16
+    int c8;                 // Ka / 8: 32-byte units per pixel
+    unsigned inv_c8, inv_hc, inv_hri;
+    int units;              // G * HRi * HC * c8
+    int ntiles;             // 32-filter tiles of the prepared filter
+};
+
+__device__ __forceinline__ void ssplit8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
+    sbf16x8 h, l;
+    h[0] = (__bf16)a.x; h[1] = (__bf16)a.y; h[2] = (__bf16)a.z; h[3] = (__bf16)a.w;
+    h[4] = (__bf16)b.x; h[5] = (__bf16)b.y; h[6] = (__bf16)b.z; h[7] = (__bf16)b.w;
+    l[0] = (__bf16)(a.x - (float)h[0]); l[1] = (__bf16)(a.y - (float)h[1]); l[2] = (__bf16)(a.z - (float)h[2]); l[3] = (__bf16)(a.w - (float)h[3]);
+    l[4] = (__bf16)(b.x - (float)h[4]); l[5] = (__bf16)(b.y - (float)h[5]); l[6] = (__bf16)(b.z - (float)h[6]); l[7] = (__bf16)(b.w - (float)h[7]);
+    hi = __builtin_bit_cast(uint4, h);
+    lo = __builtin_bit_cast(uint4, l);
+}
+
+template <class F, int... Is>
+__device__ __forceinline__ void sc_chain(F& f, std::integer_sequence<int, Is...>) { (void)(f(std::integral_constant<int, Is>{}) && ...); }
+
+__global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int R = 8;                                  // filter ring: R - 1 steps of look-ahead
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int b = blockIdx.x;
+    const int th_i = b % x.tiles_h;
+    const int n = (b / x.tiles_h) * x.G;                  // first image of the tile
+    const int oh0 = th_i * x.TH;
+    const int n0 = blockIdx.y * 32;
+    const int ph = blockIdx.z;                            // output phase (0 for single-phase problems)
+    const int tap_lo = p.tap_begin[ph], tap_hi = p.tap_begin[ph + 1];
+
+    // ---- this wave's steps of the reduction: ks = ks0 + wave, + 4, ...  (ks = tap * nk16 + 16-channel group)
+    const int ks0 = tap_lo * x.nk16 + wave;
+    const int nsteps = (tap_hi - tap_lo) * x.nk16;
+    const int n_w = nsteps > wave ? (nsteps - wave + 3) >> 2 : 0;
+    uint4 rhi[R], rlo[R];
+    const int wf_bytes = (x.nsteps >> 1) * x.ntiles * 4096;       // nk16 is even: two steps per 32-channel chunk
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Wf), 0, wf_bytes, 0x00020000);
+    const int wlane = lane * 16;
+    auto load_b = [&](uint4& hi, uint4& lo, int i) {
+        i = i < n_w ? i : n_w - 1;                                   // look-ahead past the end re-reads the last step
+        const int ks = ks0 + 4 * i;
+        const int so = ((ks >> 1) * x.ntiles + (int)blockIdx.y) * 4096 + (ks & 1) * 2048;
+        hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+        lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
+    };
+    if (n_w > 0) {
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u) load_b(rhi[u], rlo[u], u);  // in flight under the halo staging
+    }
+
+    // ---- halo of the tile, all channels: fp32 global -> bf16 hi | lo units in LDS
+    {
+        const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = x.dw_min;
+        constexpr int UB = 6;                                       // units (2 x 16 bytes) per thread and round
+        for (int base = 0; base < x.units; base += 256 * UB) {
+            float4 v[UB][2];
+            int lofs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int pix = (int)__umulhi((unsigned)idx, x.inv_c8), cu = idx - pix * x.c8;
+                const int hrv = (int)__umulhi((unsigned)pix, x.inv_hc), hc = pix - hrv * x.HC;
+                const int g = x.G > 1 ? (int)__umulhi((unsigned)hrv, x.inv_hri) : 0;
+                const int hr = hrv - g * x.HRi;
+                const int ih = ih0 + hr, iw = iw0 + hc;
+                const bool ok = idx < x.units && n + g < p.N && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+                const float* src = ok ? p.A + (int64_t)(((n + g) * p.Ha + ih) * p.Wa + iw) * p.a_ld + cu * 8 : p.A;
+                const float4 t0 = reinterpret_cast<const float4*>(src)[0], t1 = reinterpret_cast<const float4*>(src)[1];
+                v[u][0] = ok ? t0 : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u][1] = ok ? t1 : make_float4(0.f, 0.f, 0.f, 0.f);
+                lofs[u] = idx < x.units ? pix * x.PS + cu * 32 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (lofs[u] >= 0) {
+                    uint4 hi, lo;
+                    ssplit8(v[u][0], v[u][1], hi, lo);
+                    *reinterpret_cast<uint4*>(lds + lofs[u]) = hi;
+                    *reinterpret_cast<uint4*>(lds + lofs[u] + 16) = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- A-operand addressing: pixel li of the tile, channel unit lh of a step; the tap part comes from lane `tap` of lane_off
+    int a_base;
+    {
+        const int g = li >> x.slot_shift, pr = li & ((1 << x.slot_shift) - 1);
+        const int tr = pr >> x.tw_shift, tc = pr & ((1 << x.tw_shift) - 1);
+        a_base = ((g * x.HRi + tr * p.sa_h) * x.HC + tc * p.sa_w) * x.PS + lh * 32;
+    }
+    int lane_off;
+    {
+        const IgemmTap tap = p.taps[lane < 36 ? lane : 0];
+        lane_off = ((tap.dh - x.dh_min) * x.HC + (tap.dw - x.dw_min)) * x.PS;
+    }
+    auto step_off = [&](int i) {                                  // LDS byte offset (tap + channel group) of step i of this wave
+        const int ks = ks0 + 4 * i;
+        const int t = (int)__umulhi((unsigned)ks, x.inv_nk16);
+        return __builtin_amdgcn_readlane(lane_off, t) + (ks - t * x.nk16) * 64;
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    uint4 ab[2][2];                                                 // [buffer][hi, lo]
+    auto read_a = [&](int buf, int aoff) {
+        const unsigned char* ap = lds + a_base + aoff;
+        ab[buf][0] = *reinterpret_cast<const uint4*>(ap);
+        ab[buf][1] = *reinterpret_cast<const uint4*>(ap + 16);
+    };
+    if (n_w > 0) read_a(0, step_off(0));
+    // step I of this wave; false = past the end (the && fold below leaves the chain there)
+    auto step = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i >= n_w) return false;
+        load_b(rhi[(i + R - 1) % R], rlo[(i + R - 1) % R], i + R - 1);
+        if (i + 1 < n_w) read_a((i + 1) & 1, step_off(i + 1));
+        __builtin_amdgcn_sched_barrier(0);                        // keep the look-ahead loads in front of this step's MFMAs
+        const sbf16x8 ah = __builtin_bit_cast(sbf16x8, ab[i & 1][0]), al = __builtin_bit_cast(sbf16x8, ab[i & 1][1]);
+        const sbf16x8 bh = __builtin_bit_cast(sbf16x8, rhi[i % R]), bl = __builtin_bit_cast(sbf16x8, rlo[i % R]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        return true;
+    };
+    sc_chain(step, std::make_integer_sequence<int, SC_MAXSTEPS>{});
+
+    // ---- the four waves' partial tiles: exchanged through LDS, added in the order wave 0, 1, 2, 3
+    __syncthreads();                                                // every wave is past its last halo read
+    float* const xch = reinterpret_cast<float*>(lds);
+    const int col = n0 + li;
+    const float bias = (p.bias && col < p.Cc) ? p.bias[col] : 0.f;
+    const int phh = ph / p.so_w, phw = ph % p.so_w;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    // wave w finishes accumulator registers 4 w .. 4 w + 3 (pixels 8 w + 4 lh + j of the tile)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave * 4 + j;
+        const float v = ((xch[(0 * 16 + r) * 64 + lane] + xch[(1 * 16 + r) * 64 + lane]) + xch[(2 * 16 + r) * 64 + lane]) + xch[(3 * 16 + r) * 64 + lane];
+        const int q = j + 8 * wave + 4 * lh;
+        const int g = q >> x.slot_shift, pr = q & ((1 << x.slot_shift) - 1);
+        const int tr = pr >> x.tw_shift, tc = pr & ((1 << x.tw_shift) - 1);
+        if (n + g < p.N && col < p.Cc) {
+            const int64_t pix = (int64_t)((n + g) * p.Hc + (oh0 + tr) * p.so_h + phh) * p.Wc + tc * p.so_w + phw;
+            float o = act_apply(v + bias, p.act, p.leak);
+            if (p.gact != MV3D_ACT_NONE) o *= act_grad_from_out(p.gref[pix * p.g_ld + col], p.gact, p.gleak);
+            p.Out[pix * p.c_ld + col] = o;
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+static unsigned inv32(int d) { return (unsigned)((((uint64_t)1 << 32) + d - 1) / (uint64_t)d); }
+
+// returns MV3D_OK after dispatching, 1 when the problem is not one of this kernel's
+int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes) {
+    const int nph = p.so_h * p.so_w;
+    if (nph != 1 && nph != 4) return 1;
+    if (p.fold || p.Ka % 16 != 0 || p.Ka < 32 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15) || p.Cc < 16) return 1;
+    const int Hp = p.Hp[0], Wp = p.Wp[0];
+    if (nph == 4 && (p.so_h != 2 || p.so_w != 2 || p.Hp[1] != Hp || p.Wp[1] != Wp)) return 1;
+    const int ipx = Hp * Wp;
+    if ((ipx & (ipx - 1)) || (Wp & (Wp - 1)) || Wp < 4 || Wp > 32 || ipx < 16 || ipx > 64) return 1;
+    const int ntaps = p.tap_begin[nph];
+    if (ntaps < 2 || ntaps > 36) return 1;
+    for (int ph = 0; ph < nph; ++ph) if (p.tap_begin[ph + 1] == p.tap_begin[ph]) return 1;
+    int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
+    for (int t = 0; t < ntaps; ++t) {
+        dh_min = std::min<int>(dh_min, p.taps[t].dh); dh_max = std::max<int>(dh_max, p.taps[t].dh);
+        dw_min = std::min<int>(dw_min, p.taps[t].dw); dw_max = std::max<int>(dw_max, p.taps[t].dw);
+    }
+    SconvParams x = {};
+    if (ipx == 16) { x.G = 2; x.TH = Hp; x.tiles_h = 1; }
+    else { x.G = 1; x.TH = 32 / Wp; x.tiles_h = Hp / x.TH; }
+    if (x.TH < 1 || x.TH * x.tiles_h != Hp) return 1;
+    x.tw_shift = 0; while ((1 << x.tw_shift) < Wp) ++x.tw_shift;
+    x.slot_shift = 0; while ((1 << x.slot_shift) < x.TH * Wp) ++x.slot_shift;
+    if ((x.G << x.slot_shift) != 32) return 1;
+    x.HRi = (x.TH - 1) * p.sa_h + (dh_max - dh_min + 1);
+    x.HC = (Wp - 1) * p.sa_w + (dw_max - dw_min + 1);
+    x.PS = p.Ka * 4 + 32;
+    x.dh_min = dh_min; x.dw_min = dw_min;
+    x.nk16 = p.Ka / 16;
+    if (x.nk16 & 1) return 1;                                       // the prepared filter is laid out in 32-channel chunks
+    x.inv_nk16 = inv32(x.nk16);
+    x.nsteps = ntaps * x.nk16;
+    x.c8 = p.Ka / 8; x.inv_c8 = inv32(x.c8); x.inv_hc = inv32(x.HC); x.inv_hri = inv32(x.HRi);
+    x.units = x.G * x.HRi * x.HC * x.c8;
+    if (x.units >= 65536) return 1;                                 // the multiply-high divisions are exact below 2^16
+    for (int ph = 0; ph < nph; ++ph) if (cdiv((p.tap_begin[ph + 1] - p.tap_begin[ph]) * x.nk16, 4) > SC_MAXSTEPS) return 1;
+    const size_t halo = (size_t)x.G * x.HRi * x.HC * x.PS;
+    const size_t lds = std::max(halo, (size_t)16 * 1024);
+    if (lds > 160 * 1024) return 1;
+    int rc = MV3D_OK;
+    const uint4* wf = bconv_get_filter(p, ws, ws_bytes, stream, &x.ntiles, &rc);
+    if (!wf) return rc;
+    const dim3 grid(cdiv(p.N, x.G) * x.tiles_h, cdiv(p.Cc, 32), nph);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (getenv("MV3D_TRACE"))
+        fprintf(stderr, "[mv3d] %-22s sconv<%dph> N=%d in %dx%dx%d (stride %d) out %dx%dx%d taps=%d tile %dx%dx%d halo %dx%d lds=%zu grid=%dx%dx%d %.2f GFLOP\n",
+                who, nph, p.N, p.Ha, p.Wa, p.Ka, p.sa_h, p.Hc, p.Wc, p.Cc, ntaps, x.G, x.TH, Wp, x.G * x.HRi, x.HC, lds, grid.x, grid.y, grid.z, flops * 1e-9);
+    const IgemmParams pc = p;
+    return dispatch(stream, OpInfo{nph == 4 ? "sconv<4ph,32px,N32>" : "sconv<1ph,32px,N32>", flops, bytes}, [=](hipStream_t s) {
+        sconv_kernel<<<grid, 256, lds, s>>>(pc, x, wf);
+        return launched(who);
+    });
+}
+
+}  // namespace mv3d

@@ -313,6 +313,17 @@ def test_round1_kernels_at_batch_64():
         L().set_diagnostics(old)
 
 
+def test_split_k_small_image_rung_at_batch_64():
+    """diagnostics 16777216: the 8 x 8 / 4 x 4 layers on the kernels sconv replaced (chunks split over workgroups + split-K
+    epilogue launch) stay a fallback rung and stay correct at the benchmarked shapes"""
+    old = L().set_diagnostics(16777216)
+    try:
+        for i in (7, 8, 9, 10):          # e3_0 / d4_0, e4, e4_0, d4
+            run_conv_case(LC.APPFLOW_B64[i])
+    finally:
+        L().set_diagnostics(old)
+
+
 def test_model_step_at_benchmark_batch():
     """Whole AppearanceFlowModel at batch 64 (BASELINE config 2, what bench.py times): forward outputs, loss and all 47
     gradients against the oracle graph on the same inputs and weights -- the product's own plans (prepared-filter cache,
