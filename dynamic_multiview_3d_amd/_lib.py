@@ -110,6 +110,7 @@ OTHER_FUNCS = {
     "mv3d_fc_wgrad_adam_supported": (_i, [_i, _i, _i, _i, _i]),
     "mv3d_debug_cconv_stamps": (_i, [_vp, _sz]),
     "mv3d_debug_cwgrad_stamps": (_i, [_vp, _sz]),
+    "mv3d_debug_band_stamps": (_i, [_vp, _sz]),
 }
 EXPORTS = sorted(list(STATUS_FUNCS) + list(OTHER_FUNCS))
 

@@ -16,6 +16,7 @@ UNITS = {
     "bconv.hip": [],
     "cconv.hip": (["-DCC_TAP_STAMPS"] if os.environ.get("MV3D_CC_TAP_STAMPS") else []),
     "sconv.hip": [],
+    "thin.hip": [],
     "wgrad_tile.hip": [],
     "fc.hip": [],
     "elem.hip": ["-ffp-contract=off"],

@@ -1323,6 +1323,10 @@ static int img2feat(const mv3d_conv_geom* g, const void* img, const void* w, voi
     i2f_params(g, p, &pt, &pl);
     p.A = (const float*)img; p.Wt = (const float*)w; p.Out = (float*)feat;
     fill_epilogue(p, epi);
+    if (p.fold && g->C <= 4 && !(disabled_paths() & 64)) {     // row-band kernel (thin.hip): stride 2, kw * C <= 16
+        const int brc = try_smallc_band(g, p, pt, pl, img, w, feat, stream, who, conv_flops(g), conv_bytes(g));
+        if (brc != 1) return brc;
+    }
     if (p.fold && g->C <= 4 && g->kw * g->C <= 20 && g->K <= 64 && !(disabled_paths() & 64)) {
         SmallCParams q = {};
         q.X = (const float*)img; q.Wt = (const float*)w; q.Y = (float*)feat;

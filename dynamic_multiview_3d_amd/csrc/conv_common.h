@@ -79,6 +79,10 @@ const uint4* bconv_get_filter(const IgemmParams& p, void* ws, size_t ws_bytes, v
 // partials, no epilogue launch; returns 1 when the problem is not one of its
 int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes);
 
+// thin.hip: row-band kernel for 1..3-channel image sides (stride 2); returns 1 when not applicable
+int try_smallc_band(const mv3d_conv_geom* g, const IgemmParams& ep, int pt, int pl, const void* img, const void* w, void* feat,
+                    void* stream, const char* who, double flops, double bytes);
+
 // cconv.hip: software-pipelined split-bf16 convolution (one persistent 8-wave workgroup per CU, LDS-DMA halo staging) for
 // single-phase stride-1 5x5 / 3x3 problems on images of at least 16 x 16 pixels
 bool cconv_eligible(const IgemmParams& p, int* kw_out, bool* rev_out);

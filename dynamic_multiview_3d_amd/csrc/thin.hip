@@ -1,0 +1,276 @@
+// Layers with a 1..3-channel image side at full resolution (appearance_flow_model.py:88,125: e0 = conv2d_msra(image0, 32, 5, 5, 2, 2)
+// and the flow head deconv2d_msra(d1_0, [B, 128, 128, 2], 5, 5, 2, 2); main_model.py:60,74: the depth / mask towers and heads).
+// They move ~46 MB for ~1 GFLOP: HBM-bound, and the kernels of conv.hip (one 32-pixel item per wave, operands straight from
+// global memory, thousands of short workgroups) ran at a quarter of what the bytes allow -- dispatch- and latency-bound.
+//
+// smallc_band_kernel (image -> feature direction, stride 2: conv forward of e0, data gradient of the flow / depth heads):
+//   * a workgroup owns a BAND of output rows of one image x 32 filters.  All input rows of the band are fetched at once
+//     (every load of the workgroup in flight together: one memory round trip), split into bf16 hi / lo planes in LDS;
+//   * the filter row (kw * C <= 16 contiguous elements of an NHWC row) is the reduction index of one MFMA k-step, so the A
+//     fragment of an output pixel is 16 consecutive plane elements starting at column 2 * ow - pad: four dword LDS reads per
+//     lane half (plane element 0 is column -pad, so the start 2 C ow + 8 lh is dword aligned);
+//   * the filter fragments stay in registers for the whole band; a wave walks 32-pixel tiles: 5 k-steps x 3 products, then
+//     bias / activation / gradient mask and sixteen 128-byte row stores.  No global loads inside the tile loop (forward), so
+//     the in-order vmcnt queue only ever holds stores.
+#include "conv_common.h"
+#include <algorithm>
+
+namespace mv3d {
+
+typedef __bf16 tbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tbf16x2 __attribute__((ext_vector_type(2)));
+
+struct BandParams {
+    const float* X; const float* Wt; float* Y;
+    int N, H, W, C, Ho, Wo, K, y_ld;
+    int kh, kw, sh, sw, pt, pl;
+    int RB;                  // output rows per band
+    int nrows;               // input rows per band: (RB - 1) * sh + kh
+    int xoff;                // plane element of input element 0 = pl * C (so that fragment starts, 2 C ow + 8 lh, are dword aligned)
+    int rp;                  // plane row pitch in elements (even)
+    int bands_per_img, wtiles;
+    unsigned inv_row_f4;     // ceil(2^32 / (W * C / 4)): exact quotients for indices below 2^16
+    const float* bias; int act; float leak;
+    int gact; float gleak; const float* gref; int g_ld;
+    int dbg;                 // MV3D_DBG bit 32: in-kernel stamps
+};
+
+__device__ __forceinline__ unsigned tpack2(float a, float b) {
+    tbf16x2 v; v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// In-kernel stamps (MV3D_DBG bit 32 only): wave w of workgroup b < 512 writes the shader clock of event k to t_stamps[(b * 4 + w) * 16 + k];
+// read back with mv3d_debug_band_stamps().  No output value depends on them.
+__device__ unsigned long long t_stamps[512 * 4 * 16];
+__device__ __forceinline__ void tstamp(bool on, int wave, int lane, int& k) {
+    if (on) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (lane == 0 && k < 16 && blockIdx.x < 512 && blockIdx.y == 0) t_stamps[((int)blockIdx.x * 4 + wave) * 16 + k] = t;
+        ++k;
+    }
+}
+
+template <int KH, bool HAS_G>
+__global__ __launch_bounds__(256) void smallc_band_kernel(const BandParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ __attribute__((aligned(16))) uint4 fsh[KH][2][64];          // [filter row][hi, lo][lane]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int Cf = p.kw * p.C;                                             // <= 16
+    const int k0 = blockIdx.y * 32;
+    const int band = blockIdx.x % p.bands_per_img, n = blockIdx.x / p.bands_per_img;
+    const int oh0 = band * p.RB;
+    const int plane_bytes = p.nrows * p.rp * 2;
+    const bool st = (p.dbg & 32) != 0;
+    int sk = 0;
+    tstamp(st, wave, lane, sk);                                            // 0: start
+    unsigned char* const hi_pl = lds;
+    unsigned char* const lo_pl = lds + plane_bytes;
+
+    // ---- filter rows -> fragments (split once per workgroup, through LDS; first, so that its loads overlap the rows')
+    for (int pr = wave; pr < KH; pr += 4) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = 8 * lh + j;
+            v[j] = (e < Cf && k0 + li < p.K) ? p.Wt[((int64_t)pr * Cf + e) * p.K + k0 + li] : 0.f;
+        }
+        tbf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
+        fsh[pr][0][lane] = __builtin_bit_cast(uint4, h);
+        fsh[pr][1][lane] = __builtin_bit_cast(uint4, l);
+    }
+    // ---- the band's input rows: fp32 global -> bf16 hi | lo planes (all loads of the workgroup in flight together)
+    {
+        const int row_f4 = (p.W * p.C) >> 2;                               // float4 pieces per input row
+        const int total = p.nrows * row_f4;
+        const int ih0 = oh0 * p.sh - p.pt;
+        constexpr int UB = 8;
+        for (int base = 0; base < total; base += 256 * UB) {
+            float4 v[UB];
+            int lofs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int r = (int)__umulhi((unsigned)idx, p.inv_row_f4), f = idx - r * row_f4;
+                const int ih = ih0 + r;
+                const bool ok = idx < total && (unsigned)ih < (unsigned)p.H;
+                const float4 t = *reinterpret_cast<const float4*>(p.X + (ok ? ((int64_t)(n * p.H + ih) * p.W * p.C + 4 * f) : 0));
+                v[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                lofs[u] = idx < total ? (r * p.rp + p.xoff + 4 * f) * 2 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (lofs[u] >= 0) {
+                    const float h0 = (float)(__bf16)v[u].x, h1 = (float)(__bf16)v[u].y, h2 = (float)(__bf16)v[u].z, h3 = (float)(__bf16)v[u].w;
+                    const unsigned a = tpack2(v[u].x, v[u].y), b = tpack2(v[u].z, v[u].w);
+                    const unsigned c = tpack2(v[u].x - h0, v[u].y - h1), d = tpack2(v[u].z - h2, v[u].w - h3);
+                    if (p.xoff & 1) {          // rows start on an odd plane element (pad * C odd): 2-byte aligned pieces
+                        unsigned short* hp = reinterpret_cast<unsigned short*>(hi_pl + lofs[u]);
+                        unsigned short* lp = reinterpret_cast<unsigned short*>(lo_pl + lofs[u]);
+                        hp[0] = (unsigned short)a; hp[1] = (unsigned short)(a >> 16); hp[2] = (unsigned short)b; hp[3] = (unsigned short)(b >> 16);
+                        lp[0] = (unsigned short)c; lp[1] = (unsigned short)(c >> 16); lp[2] = (unsigned short)d; lp[3] = (unsigned short)(d >> 16);
+                    } else {
+                        *reinterpret_cast<unsigned*>(hi_pl + lofs[u]) = a;
+                        *reinterpret_cast<unsigned*>(hi_pl + lofs[u] + 4) = b;
+                        *reinterpret_cast<unsigned*>(lo_pl + lofs[u]) = c;
+                        *reinterpret_cast<unsigned*>(lo_pl + lofs[u] + 4) = d;
+                    }
+                }
+            }
+        }
+        tstamp(st, wave, lane, sk);                                        // 1: rows split into the planes
+        // zero pads left and right of every row (columns outside the image), element by element (they need not be dword aligned)
+        const int lpad = p.xoff, per_row = p.rp - p.W * p.C;              // left pad + right pad elements (host: <= 32)
+        const int j = tid & 31;
+        if (j < per_row) {
+            const int e = j < lpad ? j : p.W * p.C + j;                    // = xoff + W * C + (j - lpad)
+            for (int r = tid >> 5; r < p.nrows; r += 8) {
+                reinterpret_cast<unsigned short*>(hi_pl)[r * p.rp + e] = 0;
+                reinterpret_cast<unsigned short*>(lo_pl)[r * p.rp + e] = 0;
+            }
+        }
+    }
+    tstamp(st, wave, lane, sk);                                            // 2: pads zeroed
+    tstamp(st, wave, lane, sk);                                            // 3: filter fragments written
+    __syncthreads();
+    tstamp(st, wave, lane, sk);                                            // 4: barrier passed
+    tbf16x8 bh[KH], bl[KH];
+#pragma unroll
+    for (int pr = 0; pr < KH; ++pr) {
+        bh[pr] = __builtin_bit_cast(tbf16x8, fsh[pr][0][lane]);
+        bl[pr] = __builtin_bit_cast(tbf16x8, fsh[pr][1][lane]);
+    }
+
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((int64_t)p.N * p.Ho * p.Wo * p.y_ld * 4), 0x00020000);
+    const float bias = (p.bias && k0 + li < p.K) ? p.bias[k0 + li] : 0.f;
+    const int out_lane = k0 + li < p.K ? (4 * lh * p.y_ld + k0 + li) * 4 : (int)0x80000000;     // filters beyond K: stores dropped by the bounds check
+    const float c1 = p.act == MV3D_ACT_NONE ? 1.f : (p.act == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.leak) : 0.5f);
+    const float c2 = p.act == MV3D_ACT_NONE ? 0.f : (p.act == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.leak) : 0.5f);
+    const bool is_relu = p.act == MV3D_ACT_RELU;
+    const float g1 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.gleak) : 0.5f;
+    const float g2 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.gleak) : 0.5f;
+    const bool g_relu = p.gact == MV3D_ACT_RELU;
+    const int ntiles = p.RB * p.wtiles;
+    // HAS_G (data gradient): the saved outputs behind the activation-gradient mask are the only global loads of the tile loop.
+    // vmcnt retires in order and counts stores, so a load issued behind a tile's stores waits for their acknowledgements
+    // (~9 k cycles per tile when that happened to every tile: in-kernel stamps); the mask values of tile t + 1 are therefore
+    // requested BEFORE the stores of tile t.  Without a mask the loop has no loads at all and never waits for a store.
+    float gm[16];
+    auto load_mask = [&](int t) {
+        if constexpr (HAS_G) {
+            const int wt = t % p.wtiles, orow = t / p.wtiles;
+            const int pix0 = (n * p.Ho + oh0 + orow) * p.Wo + wt * 32;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int px = pix0 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+                gm[q] = (t < ntiles && k0 + li < p.K) ? p.gref[(int64_t)px * p.g_ld + k0 + li] : 0.f;
+            }
+        }
+    };
+    load_mask(wave);
+    for (int t = wave; t < ntiles; t += 4) {
+        const int wt = t % p.wtiles, orow = t / p.wtiles;                  // wave-uniform
+        const int oh = oh0 + orow;
+        // first plane element of this lane's fragment: column (wt * 32 + li) * sw - pl, element 8 lh of the filter row
+        const int e0 = ((wt * 32 + li) * p.sw - p.pl) * p.C + 8 * lh + p.xoff;
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < KH; ++pr) {
+            const int off = ((orow * p.sh + pr) * p.rp + e0) * 2;
+            const unsigned* ph = reinterpret_cast<const unsigned*>(hi_pl + off);
+            const unsigned* pq = reinterpret_cast<const unsigned*>(lo_pl + off);
+            const uint4 ah4 = make_uint4(ph[0], ph[1], ph[2], ph[3]), al4 = make_uint4(pq[0], pq[1], pq[2], pq[3]);
+            const tbf16x8 ah = __builtin_bit_cast(tbf16x8, ah4), al = __builtin_bit_cast(tbf16x8, al4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[pr], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[pr], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[pr], acc, 0, 0, 0);
+        }
+        // branch-free epilogue (tanh is not taken here: try_smallc_band): y = c1 x + c2 |x| as tf_utils.py:25-33 writes it (two
+        // products, one sum; relu keeps -0.0 for x < 0), the mask from the saved output as common.h act_grad_from_out
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float xv = acc[q] + bias;
+            float y = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
+            y = (is_relu && xv < 0.0f) ? -0.0f : y;
+            if constexpr (HAS_G) {
+                const float go = gm[q];
+                const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
+                const float sgn = go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f);
+                y *= g1 + g2 * sgn;
+            }
+            v[q] = y;
+        }
+        load_mask(t + 4);                                                  // next tile's mask values: in front of this tile's stores
+        __builtin_amdgcn_sched_barrier(0);
+        const int pix0 = (n * p.Ho + oh) * p.Wo + wt * 32;                 // wave-uniform: first pixel of the tile
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int px = pix0 + (q & 3) + 8 * (q >> 2);                  // + 4 lh in the lane part
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), yr, out_lane, px * p.y_ld * 4, 0);
+        }
+        tstamp(st, wave, lane, sk);                                        // 5 + i: tile i done (stores issued)
+    }
+    if (st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tstamp(st, wave, lane, sk); }      // last: stores acknowledged
+}
+
+// returns MV3D_OK after dispatching, 1 when the problem is not one of this kernel's (the caller falls back to smallc_b3*)
+int try_smallc_band(const mv3d_conv_geom* g, const IgemmParams& ep, int pt, int pl, const void* img, const void* w, void* feat,
+                    void* stream, const char* who, double flops, double bytes) {
+    if (disabled_paths() & (4096 | 33554432)) return 1;
+    if (g->C > 4 || g->img_ld != g->C || g->kw * g->C > 16 || (g->kh != 5 && g->kh != 3) || g->sh != 2 || g->sw != 2) return 1;
+    if (g->Wo % 32 != 0 || g->K % 32 != 0 || (g->W * g->C) % 4 != 0 || (reinterpret_cast<uintptr_t>(img) & 15)) return 1;
+    if ((int64_t)g->N * g->Ho * g->Wo * g->feat_ld * 4 >= 0x7fffffff) return 1;
+    if (ep.gact != MV3D_ACT_NONE && !ep.gref) return 1;
+    if (ep.act == MV3D_ACT_TANH || ep.gact == MV3D_ACT_TANH) return 1;
+    BandParams p = {};
+    p.X = (const float*)img; p.Wt = (const float*)w; p.Y = (float*)feat;
+    p.N = g->N; p.H = g->H; p.W = g->W; p.C = g->C; p.Ho = g->Ho; p.Wo = g->Wo; p.K = g->K; p.y_ld = g->feat_ld;
+    p.kh = g->kh; p.kw = g->kw; p.sh = g->sh; p.sw = g->sw; p.pt = pt; p.pl = pl;
+    p.xoff = pl * g->C;
+    // a fragment reads 16 elements from (2 ow - pl) * C + xoff: the last one ends at most 16 elements past the row
+    p.rp = (p.xoff + g->W * g->C + 16 + 1) & ~1;
+    p.wtiles = g->Wo / 32;
+    p.inv_row_f4 = (unsigned)((((uint64_t)1 << 32) + (g->W * g->C / 4) - 1) / (uint64_t)(g->W * g->C / 4));
+    // band height: at least 512 workgroups when the layer has them, planes of at most 60 KiB (two workgroups per CU)
+    int rb = 16;
+    while (rb > 1 && (g->Ho % rb != 0 || (int64_t)g->N * (g->Ho / rb) * (g->K / 32) < 512 || (size_t)((rb - 1) * g->sh + g->kh) * p.rp * 4 > 60 * 1024)) rb >>= 1;
+    if (g->Ho % rb != 0) return 1;
+    p.RB = rb;
+    p.nrows = (rb - 1) * g->sh + g->kh;
+    p.bands_per_img = g->Ho / rb;
+    const size_t lds = (size_t)p.nrows * p.rp * 4;
+    if (lds > 120 * 1024 || p.rp - g->W * g->C > 32 || p.nrows * (g->W * g->C / 4) >= 65536) return 1;
+    { static int d = -1; if (d < 0) { const char* e = getenv("MV3D_DBG"); d = e ? atoi(e) : 0; } p.dbg = d; }
+    p.bias = ep.bias; p.act = ep.act; p.leak = ep.leak; p.gact = ep.gact; p.gleak = ep.gleak; p.gref = ep.gref; p.g_ld = ep.g_ld;
+    const dim3 grid(g->N * p.bands_per_img, g->K / 32, 1);
+    const bool k5 = g->kh == 5, hg = ep.gact != MV3D_ACT_NONE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_band_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_band_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_band_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&smallc_band_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    return dispatch(stream, OpInfo{hg ? "smallc_band<gmask>" : "smallc_band", flops, bytes}, [=](hipStream_t s) {
+        if (k5) { if (hg) smallc_band_kernel<5, true><<<grid, 256, lds, s>>>(p); else smallc_band_kernel<5, false><<<grid, 256, lds, s>>>(p); }
+        else { if (hg) smallc_band_kernel<3, true><<<grid, 256, lds, s>>>(p); else smallc_band_kernel<3, false><<<grid, 256, lds, s>>>(p); }
+        return launched(who);
+    });
+}
+
+}  // namespace mv3d
+
+extern "C" int mv3d_debug_band_stamps(void* dst, size_t bytes) {
+    if (!dst || bytes > sizeof(unsigned long long) * 512 * 4 * 16) return mv3d::fail(MV3D_E_INVAL, "mv3d_debug_band_stamps: bad buffer");
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv3d::t_stamps), bytes, 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_debug_band_stamps: %s", hipGetErrorString(e));
+    return MV3D_OK;
+}

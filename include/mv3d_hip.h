@@ -302,6 +302,8 @@ int mv3d_plan_op_info(const mv3d_plan* p, int i, const char** name, double* flop
 int mv3d_debug_cconv_stamps(void* host_dst, size_t bytes);
 /* the same for the pipelined filter-gradient kernel (cwgrad): [128 slabs][8 waves][64 events] of the workgroups with blockIdx.x == 0 */
 int mv3d_debug_cwgrad_stamps(void* host_dst, size_t bytes);
+/* the same for the row-band kernel of the thin input layers (thin.hip): [workgroup < 512][wave 4][16] uint64 */
+int mv3d_debug_band_stamps(void* host_dst, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -324,6 +324,17 @@ def test_split_k_small_image_rung_at_batch_64():
         L().set_diagnostics(old)
 
 
+def test_per_item_thin_input_rung_at_batch_64():
+    """diagnostics 33554432: the 3- / 2-channel input layers on the per-item kernels the row-band kernel replaced
+    (smallc_b3s / smallc_b3) stay a fallback rung and stay correct at the benchmarked shapes"""
+    old = L().set_diagnostics(33554432)
+    try:
+        run_conv_case(LC.APPFLOW_B64[0])           # e0
+        run_conv_case(LC.APPFLOW_B64[15])          # flow_field (its data gradient is the thin image -> feature direction)
+    finally:
+        L().set_diagnostics(old)
+
+
 def test_model_step_at_benchmark_batch():
     """Whole AppearanceFlowModel at batch 64 (BASELINE config 2, what bench.py times): forward outputs, loss and all 47
     gradients against the oracle graph on the same inputs and weights -- the product's own plans (prepared-filter cache,
