@@ -1444,6 +1444,10 @@ int set_wgrad_cus(int cus);
 
 static size_t filtgrad_ws_bytes(const mv3d_conv_geom* g) {
     {
+        const int tw = thin_wgrad_slabs(g);
+        if (tw > 0) return (size_t)tw * ((size_t)g->kh * g->kw * g->C * g->K + g->K) * sizeof(float);
+    }
+    {
         ThinFgParams tp; int ns; size_t lds;
         if (thin_filtgrad_plan(g, tp, &ns, &lds)) return (size_t)ns * ((size_t)g->kh * g->kw * g->C * g->K + g->K) * sizeof(float);
     }
@@ -1479,6 +1483,18 @@ static int filtgrad(const mv3d_conv_geom* g, const void* img, const void* feat, 
             if (rc == MV3D_OK && ns == 1 && finalize_collecting()) { finalize_push(nullptr, 0, fcount, dfp); if (dbp) finalize_push(nullptr, 0, K, dbp); }
             if (rc != MV3D_OK || ns == 1) return rc;
             return dispatch_reduce(stream, part, ns, fcount, dfp, bpart, K, dbp);
+        }
+    }
+    {   // 1..3 image-side channels, stride 2: matrix-core band kernel (thin.hip)
+        const int tw = thin_wgrad_slabs(g);
+        if (tw > 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0) {
+            const size_t need = (size_t)tw * (fcount + K) * sizeof(float);
+            if (!ws || ws_bytes < need) return fail(MV3D_E_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, need);
+            float* part = (float*)ws;
+            float* bpart = db ? (float*)ws + (int64_t)tw * fcount : nullptr;
+            rc = thin_wgrad_launch(g, img, feat, part, bpart, stream, who, conv_flops(g), conv_bytes(g));
+            if (rc == MV3D_OK) return dispatch_reduce(stream, part, tw, fcount, dfp, bpart, K, dbp);
+            if (rc != 1) return rc;
         }
     }
     {   // 1..4 image-side channels: streaming VALU kernel

@@ -83,6 +83,11 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
 int try_smallc_band(const mv3d_conv_geom* g, const IgemmParams& ep, int pt, int pl, const void* img, const void* w, void* feat,
                     void* stream, const char* who, double flops, double bytes);
 
+// thin.hip: matrix-core filter gradient of the same layers: slabs (0 = not applicable) and launch (partials [slab][filter] + [slab][K])
+int thin_wgrad_slabs(const mv3d_conv_geom* g);
+int thin_wgrad_launch(const mv3d_conv_geom* g, const void* img, const void* feat, void* part, void* bias_part, void* stream,
+                      const char* who, double flops, double bytes);
+
 // cconv.hip: software-pipelined split-bf16 convolution (one persistent 8-wave workgroup per CU, LDS-DMA halo staging) for
 // single-phase stride-1 5x5 / 3x3 problems on images of at least 16 x 16 pixels
 bool cconv_eligible(const IgemmParams& p, int* kw_out, bool* rev_out);

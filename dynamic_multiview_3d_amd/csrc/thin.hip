@@ -274,3 +274,269 @@ extern "C" int mv3d_debug_band_stamps(void* dst, size_t bytes) {
     if (e != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_debug_band_stamps: %s", hipGetErrorString(e));
     return MV3D_OK;
 }
+
+namespace mv3d {
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Filter gradient of the same layers (Conv2DBackpropFilter of e0; of the flow / depth heads with the roles of x and dy swapped):
+//   dW[r][e][k] = sum_{n, oh, ow} X[n][2 oh + r - pt][(2 ow - pl) C + e] * dY[n][oh][ow][k],   e = dw * C + c < kw * C <= 16
+// 1 GFLOP over 46 MB.  thin_filtgrad_kernel (conv.hip) does it with rank-1 updates on the vector ALUs (43 us: VALU- and
+// latency-bound); here it is three products per fp32 product on the matrix cores with the PIXELS of an output row as the
+// reduction index:
+//   * a workgroup owns a band of eight output rows of one image; its 19 input rows are fetched once and scattered into
+//     S[input row][e][ow] = X[row][(2 ow - pl) C + e] (bf16 hi / lo planes): the sequence a filter element sees along an output
+//     row, contiguous in ow -- so an A fragment (8 consecutive pixels of one (r, e)) is ONE 16-byte LDS read.  An M tile is two
+//     filter rows x 16 elements; the e-pitch of 72 elements spreads the 16 rows of a lane group over all banks;
+//   * dY goes straight from global memory into B fragments: lane (filter k, half h) loads the 8 pixels of its k -- each value
+//     is needed by exactly one wave, so LDS would only add a pass.  The bias gradient is the sum of what a lane loaded;
+//   * a wave takes every fourth output row: 4 k-steps x 3 M tiles x 3 products per row, accumulators in registers; the four
+//     waves' partial filters meet in LDS (fixed order) and leave as this workgroup's slab of the partial-filter buffer.
+struct ThinWgParams {
+    const float* img; const float* feat; float* out; float* bias_out;
+    int N, H, W, C, Ho, Wo, K, feat_ld;
+    int kh, kw, pt, pl;
+    int RB, nrows, ep;            // band height, input rows per band, e-pitch of S in elements (Wo + 8)
+    int rp;                       // pitch of the linear rows in elements: pl * C + W * C + 16, even
+    unsigned inv_row_f4;
+    int bands_per_img, dbg;
+    unsigned inv_per_row, inv_hw;   // ceil(2^32 / (kw C Wo / 2)), ceil(2^32 / (Wo / 2))
+};
+
+template <int KH>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinWgParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int MTL = (KH + 1) / 2;                                      // M tiles: pairs of filter rows
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int Cf = p.kw * p.C;
+    const int k0 = blockIdx.y * 32;
+    const int band = blockIdx.x % p.bands_per_img, n = blockIdx.x / p.bands_per_img;
+    const int oh0 = band * p.RB;
+    const int plane_el = (p.nrows + 1) * 16 * p.ep;                        // elements per plane (+ one zero row: the odd filter row of the last M tile)
+    unsigned short* const s_hi = reinterpret_cast<unsigned short*>(lds);
+    unsigned short* const s_lo = s_hi + plane_el;
+
+    const bool st = (p.dbg & 32) != 0;
+    int sk = 0;
+    tstamp(st, wave, lane, sk);                                            // 0 start
+    constexpr int PF = 4;                                                  // k-steps of dY prefetched (64 pixels)
+    const bool k_ok = k0 + li < p.K;
+    float pre[PF][8];
+    tstamp(st, wave, lane, sk);                                            // 1 dY requested
+    // ---- build the planes in two steps.  (1) the band's input rows, coalesced 16-byte loads -> linear bf16 hi / lo rows in LDS
+    // (element 0 = column -pl, zero pads left and right, zero rows outside the image); (2) LDS -> LDS: every entry
+    // S[ir][e][ow] = row[2 C ow + e], two 2-byte reads and one packed 4-byte store per pair of consecutive ow and plane.
+    // (Building S straight from global memory was tried both ways: scattering coalesced row loads costs three positions of
+    // index arithmetic and 2-byte stores per element, gathering with 4-byte loads 24 bytes apart keeps the texture path busy
+    // for 15 k cycles per band -- in-kernel stamps.)
+    unsigned short* const l_hi = s_lo + plane_el;
+    unsigned short* const l_lo = l_hi + p.nrows * p.rp;
+    {
+        const int row_f4 = (p.W * p.C) >> 2;
+        const int total = p.nrows * row_f4;
+        const int ih0 = oh0 * 2 - p.pt;
+        const int xoff = p.pl * p.C;
+        constexpr int UB = 5;
+        for (int base = 0; base < total; base += 256 * UB) {
+            float4 v[UB];
+            int lofs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int r = (int)__umulhi((unsigned)idx, p.inv_row_f4), f = idx - r * row_f4;
+                const int ih = ih0 + r;
+                const bool ok = idx < total && (unsigned)ih < (unsigned)p.H;
+                const float4 t = *reinterpret_cast<const float4*>(p.img + (ok ? ((int64_t)(n * p.H + ih) * p.W * p.C + 4 * f) : 0));
+                v[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                lofs[u] = idx < total ? r * p.rp + xoff + 4 * f : -1;
+            }
+            if (base == 0) {
+                // this wave's first output row of dY: requested BEHIND the first round of row loads (vmcnt retires in order: in
+                // front of them, the rows waited for the whole 33 MB dY stream of the layer -- 12 k cycles per band in the stamps)
+                // and consumed after the planes are built; the remaining rows of a wave are loaded row by row
+                const float* frow = p.feat + (int64_t)((n * p.Ho + min(oh0 + wave, p.Ho - 1)) * p.Wo) * p.feat_ld + k0 + li;
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pre[u][j] = (k_ok && u * 16 < p.Wo) ? frow[(int64_t)(u * 16 + 8 * lh + j) * p.feat_ld] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (lofs[u] >= 0) {
+                    const float xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const __bf16 h = (__bf16)xs[j];
+                        const __bf16 l = (__bf16)(xs[j] - (float)h);
+                        l_hi[lofs[u] + j] = __builtin_bit_cast(unsigned short, h);
+                        l_lo[lofs[u] + j] = __builtin_bit_cast(unsigned short, l);
+                    }
+                }
+            }
+        }
+        const int per_row = p.rp - p.W * p.C;                              // left + right pad elements (host: <= 32)
+        const int j = tid & 31;
+        if (j < per_row) {
+            const int e = j < xoff ? j : p.W * p.C + j;
+            for (int r = tid >> 5; r < p.nrows; r += 8) { l_hi[r * p.rp + e] = 0; l_lo[r * p.rp + e] = 0; }
+        }
+    }
+    __syncthreads();
+    {
+        const int hw = p.Wo >> 1;                                          // ow pairs per (row, element)
+        const int per_row = Cf * hw;
+        const int total = p.nrows * per_row;
+        const int c2 = 2 * p.C;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int ir = (int)__umulhi((unsigned)idx, p.inv_per_row), rem = idx - ir * per_row;
+            const int e = (int)__umulhi((unsigned)rem, p.inv_hw), owp = rem - e * hw;
+            const int t0 = ir * p.rp + 2 * c2 * owp + e;
+            const unsigned h = (unsigned)l_hi[t0] | ((unsigned)l_hi[t0 + c2] << 16);
+            const unsigned l = (unsigned)l_lo[t0] | ((unsigned)l_lo[t0 + c2] << 16);
+            const int o = (ir * 16 + e) * p.ep + 2 * owp;
+            *reinterpret_cast<unsigned*>(s_hi + o) = h;
+            *reinterpret_cast<unsigned*>(s_lo + o) = l;
+        }
+    }
+    tstamp(st, wave, lane, sk);                                            // 2 planes written
+    __syncthreads();
+    tstamp(st, wave, lane, sk);                                            // 3 barrier
+
+    f32x16 acc[MTL];
+#pragma unroll
+    for (int t = 0; t < MTL; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    float bsum = 0.f;
+    const int ksteps = p.Wo >> 4;
+    const int a_lane = (((li >> 4) * 16 + (li & 15)) * p.ep + 8 * lh) * 2;     // bytes: filter row parity, element, pixel half
+    for (int orow = wave, it = 0; orow < p.RB; orow += 4, ++it) {
+        if (oh0 + orow >= p.Ho) break;
+        for (int ks = 0; ks < ksteps; ++ks) {
+            float b[8];
+            if (it == 0 && ks < PF) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = 0.f;
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+                    if (u == ks) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) b[j] = pre[u][j];
+                    }
+            } else {
+                const float* frow = p.feat + (int64_t)((n * p.Ho + oh0 + orow) * p.Wo) * p.feat_ld + k0 + li;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = k_ok ? frow[(int64_t)(ks * 16 + 8 * lh + j) * p.feat_ld] : 0.f;
+            }
+            tbf16x8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { bh[j] = (__bf16)b[j]; bl[j] = (__bf16)(b[j] - (float)bh[j]); bsum += b[j]; }
+#pragma unroll
+            for (int t = 0; t < MTL; ++t) {
+                // M tile t: filter rows 2 t (lanes 0-15) and 2 t + 1 (lanes 16-31) -> input rows 2 orow + 2 t (+ 1)
+                const unsigned char* ap = lds + ((orow * 2 + 2 * t) * 16 * p.ep + ks * 16) * 2 + a_lane;
+                const tbf16x8 ah = __builtin_bit_cast(tbf16x8, *reinterpret_cast<const uint4*>(ap));
+                const tbf16x8 al = __builtin_bit_cast(tbf16x8, *reinterpret_cast<const uint4*>(ap + plane_el * 2));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    tstamp(st, wave, lane, sk);                                            // 4 products done
+    // ---- the four waves' partial filters: through LDS, added in the order wave 0, 1, 2, 3
+    __syncthreads();
+    tstamp(st, wave, lane, sk);                                            // 5 barrier
+    float* const xch = reinterpret_cast<float*>(lds);                      // [wave][MTL][16][64] + bias [wave][64]
+#pragma unroll
+    for (int t = 0; t < MTL; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xch[((wave * MTL + t) * 16 + q) * 64 + lane] = acc[t][q];
+    float* const bx = xch + 4 * MTL * 16 * 64;
+    bx[wave * 64 + lane] = bsum;
+    __syncthreads();
+    const int64_t fcount = (int64_t)p.kh * Cf * p.K;
+    float* const out = p.out + (int64_t)blockIdx.x * fcount;
+    // wave w finishes registers 4 w .. 4 w + 3 of every M tile
+#pragma unroll
+    for (int t = 0; t < MTL; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = wave * 4 + j;
+            const float s = ((xch[((0 * MTL + t) * 16 + q) * 64 + lane] + xch[((1 * MTL + t) * 16 + q) * 64 + lane]) +
+                             xch[((2 * MTL + t) * 16 + q) * 64 + lane]) + xch[((3 * MTL + t) * 16 + q) * 64 + lane];
+            const int m = (q & 3) + 8 * (q >> 2) + 4 * lh;                  // row of the tile: filter row parity * 16 + element
+            const int r = 2 * t + (m >> 4), e = m & 15;
+            if (r < p.kh && e < Cf && k0 + li < p.K) out[(int64_t)(r * Cf + e) * p.K + k0 + li] = s;
+        }
+    if (p.bias_out && wave == 0 && lh == 0 && k0 + li < p.K) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += bx[w * 64 + li] + bx[w * 64 + 32 + li];
+        p.bias_out[(int64_t)blockIdx.x * p.K + k0 + li] = s;
+    }
+    tstamp(st, wave, lane, sk);                                            // 6 partial filter stored
+}
+
+namespace {
+int thin_wg_rb(const mv3d_conv_geom* g) {
+    static int e = -1;
+    if (e < 0) { const char* v = getenv("MV3D_TW_RB"); e = v ? atoi(v) : 4; }
+    if (e == 8 && g->Ho % 8 == 0) return 8;
+    return g->Ho % 4 == 0 ? 4 : 0;
+}
+unsigned tinv32(int d) { return (unsigned)((((uint64_t)1 << 32) + d - 1) / (uint64_t)d); }
+}
+
+// planning: number of slabs (= workgroups along the pixels) of the matrix-core thin filter gradient, 0 when not applicable
+int thin_wgrad_slabs(const mv3d_conv_geom* g) {
+    if (disabled_paths() & (4096 | 16384 | 67108864)) return 0;
+    if (g->C > 4 || g->img_ld != g->C || g->kw * g->C > 16 || (g->kh != 5 && g->kh != 3) || g->sh != 2 || g->sw != 2) return 0;
+    if (g->Wo % 16 != 0 || g->K % 32 != 0 || (g->W * g->C) % 4 != 0 || g->W != 2 * g->Wo || g->H != 2 * g->Ho) return 0;
+    const int rb = thin_wg_rb(g);
+    if (!rb) return 0;
+    const int nrows = (rb - 1) * 2 + g->kh;
+    const size_t lds = std::max((size_t)(nrows + 1) * 16 * (g->Wo + 8) * 4 + (size_t)nrows * (g->W * g->C + 4 * g->C + 18) * 4, (size_t)(4 * 3 * 16 * 64 + 256) * 4);
+    if (lds > 150 * 1024 || nrows * g->kw * g->C * (g->Wo / 2) >= 65536 || nrows * (g->W * g->C / 4) >= 65536) return 0;
+    return g->N * (g->Ho / rb);
+}
+
+int thin_wgrad_launch(const mv3d_conv_geom* g, const void* img, const void* feat, void* part, void* bias_part, void* stream,
+                      const char* who, double flops, double bytes) {
+    if (!thin_wgrad_slabs(g)) return 1;
+    if ((reinterpret_cast<uintptr_t>(img) & 15)) return 1;
+    ThinWgParams p = {};
+    int ho, wo;
+    same_pad(g->H, g->kh, 2, &ho, &p.pt);
+    same_pad(g->W, g->kw, 2, &wo, &p.pl);
+    p.img = (const float*)img; p.feat = (const float*)feat; p.out = (float*)part; p.bias_out = (float*)bias_part;
+    p.N = g->N; p.H = g->H; p.W = g->W; p.C = g->C; p.Ho = g->Ho; p.Wo = g->Wo; p.K = g->K; p.feat_ld = g->feat_ld;
+    p.kh = g->kh; p.kw = g->kw;
+    p.RB = thin_wg_rb(g);
+    p.nrows = (p.RB - 1) * 2 + g->kh;
+    p.ep = g->Wo + 8;
+    p.bands_per_img = g->Ho / p.RB;
+    { static int d = -1; if (d < 0) { const char* e = getenv("MV3D_DBG"); d = e ? atoi(e) : 0; } p.dbg = d; }
+    p.rp = (p.pl * g->C + g->W * g->C + 16 + 1) & ~1;
+    p.inv_row_f4 = tinv32(g->W * g->C / 4);
+    p.inv_per_row = tinv32(g->kw * g->C * (g->Wo / 2));
+    p.inv_hw = tinv32(g->Wo / 2);
+    const int mtl = (g->kh + 1) / 2;
+    const size_t lds = std::max((size_t)(p.nrows + 1) * 16 * p.ep * 4 + (size_t)p.nrows * p.rp * 4, (size_t)(4 * mtl * 16 * 64 + 256) * 4);
+    const dim3 grid(g->N * p.bands_per_img, g->K / 32, 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const bool k5 = g->kh == 5;
+    return dispatch(stream, OpInfo{"thin_wgrad", flops, bytes}, [=](hipStream_t s) {
+        if (k5) thin_wgrad_kernel<5><<<grid, 256, lds, s>>>(p);
+        else thin_wgrad_kernel<3><<<grid, 256, lds, s>>>(p);
+        return launched(who);
+    });
+}
+
+}  // namespace mv3d

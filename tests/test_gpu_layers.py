@@ -325,9 +325,10 @@ def test_split_k_small_image_rung_at_batch_64():
 
 
 def test_per_item_thin_input_rung_at_batch_64():
-    """diagnostics 33554432: the 3- / 2-channel input layers on the per-item kernels the row-band kernel replaced
-    (smallc_b3s / smallc_b3) stay a fallback rung and stay correct at the benchmarked shapes"""
-    old = L().set_diagnostics(33554432)
+    """diagnostics 33554432 | 67108864: the 3- / 2-channel input layers on the kernels the row-band kernels of thin.hip
+    replaced (smallc_b3s / smallc_b3 per-item forward, thin_filtgrad on the vector ALUs) stay fallback rungs and stay correct
+    at the benchmarked shapes"""
+    old = L().set_diagnostics(33554432 | 67108864)
     try:
         run_conv_case(LC.APPFLOW_B64[0])           # e0
         run_conv_case(LC.APPFLOW_B64[15])          # flow_field (its data gradient is the thin image -> feature direction)
