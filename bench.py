@@ -354,6 +354,8 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if (os.environ.get('MV3D_DISABLE') and int(os.environ['MV3D_DISABLE']) & 4096) else "bf16x3",
         "data": "synthetic",
+        "value_note": ("all %d timed steps count, including the %d that carry HIP events on every conv / deconv launch (queue barriers: those "
+                       "steps run 10-20 %% slower); --no-kernel-timing gives the undisturbed rate" % (args.steps, n_evsteps)) if timing else "no per-kernel events inside the timed region",
         "config": {"workload": "appflow_offset: AppearanceFlowModel 128x128x3, batch %d per GPU, Adam lr 1e-4, "
                                "random-init weights (reference initialisers)" % args.batch,
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world,
@@ -422,7 +424,7 @@ def main():
                     tj = json.load(open(tfile))
                     famt = tj.get('_family', {}).get('conv')
                     if famt:      # HBM bytes per step of the family from committed rocprofv3 PMC passes (profiles/), FETCH_SIZE x2-corrected
-                        roof["traffic"] = round(famt["hbm_bytes_per_step"] / max(fam_n, 1))
+                        roof["traffic"] = round(famt["hbm_bytes_per_step"] / max(fam_n, 1))      # per average launch, like `achieved` (the per-step figure follows)
                         roof["traffic_per_step"] = famt["hbm_bytes_per_step"]
                         roof["traffic_source"] = famt.get("source")
                     roof["algorithmic_bytes_per_step"] = round(sum(k['bytes'] for k in tfam.values()))
@@ -435,6 +437,25 @@ def main():
                            "alone_gbs": round(ad['bytes'] / (ad['ms'] * 1e-3) / 1e9, 1), "alone_frac_of_hbm_peak": round(ad['bytes'] / (ad['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             if adam_in_region:
                 out["adam"].update({"in_region_ms": round(adam_in_region, 4), "in_region_gbs": round(ad['bytes'] / (adam_in_region * 1e-3) / 1e9, 1)})
+        # achieved HBM GB/s of the bandwidth-bound pieces of the path -- the sampler (fused with the loss and its
+        # gradient), the 3-channel input layer e0 and the 2-channel flow head (forward, data gradient, filter gradients), the
+        # gradient finalisation and the fused fc optimiser -- from their ALGORITHMIC bytes and own durations
+        hk = {}
+        for label, what in (('resample_loss', 'warp + bilinear sampler + pixel loss + flow gradient (tf_utils.py:35-42,18-19)'),
+                            ('smallc_band', 'e0: conv 128x128x3 -> 64x64x32, 5x5 stride 2, forward (appearance_flow_model.py:88)'),
+                            ('thin_deconv_s2<2>', 'flow_field: deconv 64x64x32 -> 128x128x2, 5x5 stride 2, forward (appearance_flow_model.py:125)'),
+                            ('smallc_band<gmask>', 'flow_field: data gradient'),
+                            ('thin_wgrad', 'filter gradients of e0 and flow_field (two launches)'),
+                            ('grad_finalize_adam', 'slab sums of all conv filter gradients + their optimiser update'),
+                            ('fc_wgrad_adam_b3', 'fc filter gradient + ApplyAdam of the matrix, 24 B per parameter (four launches)')):
+            k = table.get(label)
+            if k and k['ms'] > 0 and k['bytes'] > 0:
+                gbs = k['bytes'] / (k['ms'] * 1e-3) / 1e9
+                hk[label] = {"what": what, "launches": k['launches'], "algorithmic_mb": round(k['bytes'] / 1e6, 2), "ms": round(k['ms'], 4),
+                             "gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
+        if hk:
+            hk["_measured"] = "HIP events, warm-up steps, all launches on one stream (own durations, launch overhead included); peak %.0f GB/s" % PEAK_HBM_GBS
+            out["hbm_kernels"] = hk
         mfma = {n: k for n, k in table.items() if k['flops'] > 0}
         conv_ms = sum(k['ms'] for k in mfma.values())
         conv_fl = sum(k['flops'] for k in mfma.values())

@@ -592,6 +592,10 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
         }
     }
     if (Hp * Wp < 64 || Wp < 8) return 1;
+    if (b3 && nph == 4 && !(disabled_paths() & 16777216)) {      // stride-2 transposed convolutions: one phase per workgroup (sconv.hip, TILE)
+        const int rc = try_sconv(p, ws, ws_bytes, stream, who, flops, bytes);
+        if (rc != 1) return rc;
+    }
     if (b3) {
         // split-bf16 kernels: prefer 64 pixels x 32..64 columns per wave (operand reuse from registers); two
         // workgroups share a CU, so ask for >= 512 workgroups before settling on a tile size

@@ -38,7 +38,7 @@ constexpr int SC_MAXSTEPS = 48;      // reduction steps per wave the straight-li
 struct SconvParams {
     int TH;                 // phase-grid rows of one image slot covered by a tile
     int G;                  // image slots per tile (2: 4 x 4 phase grids, 1 otherwise)
-    int tiles_h;            // row tiles per image
+    int tiles_h, tiles_w;   // row / column tiles per image (tiles_w: TILE kernel only)
     int tw_shift;           // log2(phase-grid width)
     int slot_shift;         // log2(pixels per image slot) = log2(TH * Wp)
     int HRi, HC, PS;        // halo rows per slot, halo columns, bytes per halo pixel record (4 * Ka + 32)
@@ -65,6 +65,14 @@ __device__ __forceinline__ void ssplit8(const float4& a, const float4& b, uint4&
 template <class F, int... Is>
 __device__ __forceinline__ void sc_chain(F& f, std::integer_sequence<int, Is...>) { (void)(f(std::integral_constant<int, Is>{}) && ...); }
 
+// TILE = false: images of 16 .. 64 phase-grid pixels, 32 pixels per workgroup, reduction split over the four waves (above).
+// TILE = true: larger phase grids (the stride-2 transposed convolutions d1 / d2 and the data gradients of e1 / e2,
+// appearance_flow_model.py:90,92,117,120): a workgroup owns an 8 x 16-pixel tile of one output phase x 32 filters, each wave 32
+// of its pixels (two tile rows) for the WHOLE reduction of the phase (<= 9 taps x 64 channels) -- no exchange; the halo of the
+// tile (10 x 18 pixels x all channels, <= 50 KiB: three workgroups per CU, whose staging and multiplying phases overlap) is
+// staged once, the filter fragments stream from L2.  Replaces the fused 4-phase bconv kernel (93 TFLOP/s: staging, tap loop and
+// stores of a tile in series, two workgroups per CU) for these layers.
+template <bool TILE>
 __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int R = 8;                                  // filter ring: R - 1 steps of look-ahead
@@ -73,24 +81,27 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     int b = blockIdx.x;
+    const int tw_i = TILE ? b % x.tiles_w : 0;
+    if (TILE) b /= x.tiles_w;
     const int th_i = b % x.tiles_h;
     const int n = (b / x.tiles_h) * x.G;                  // first image of the tile
-    const int oh0 = th_i * x.TH;
+    const int oh0 = th_i * x.TH, ow0 = tw_i * 16;
     const int n0 = blockIdx.y * 32;
     const int ph = blockIdx.z;                            // output phase (0 for single-phase problems)
     const int tap_lo = p.tap_begin[ph], tap_hi = p.tap_begin[ph + 1];
 
     // ---- this wave's steps of the reduction: ks = ks0 + wave, + 4, ...  (ks = tap * nk16 + 16-channel group)
-    const int ks0 = tap_lo * x.nk16 + wave;
+    constexpr int KS = TILE ? 1 : 4;                      // step stride of a wave: all steps (TILE), or every fourth
+    const int ks0 = tap_lo * x.nk16 + (TILE ? 0 : wave);
     const int nsteps = (tap_hi - tap_lo) * x.nk16;
-    const int n_w = nsteps > wave ? (nsteps - wave + 3) >> 2 : 0;
+    const int n_w = TILE ? nsteps : (nsteps > wave ? (nsteps - wave + 3) >> 2 : 0);
     uint4 rhi[R], rlo[R];
     const int wf_bytes = (x.nsteps >> 1) * x.ntiles * 4096;       // nk16 is even: two steps per 32-channel chunk
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Wf), 0, wf_bytes, 0x00020000);
     const int wlane = lane * 16;
     auto load_b = [&](uint4& hi, uint4& lo, int i) {
         i = i < n_w ? i : n_w - 1;                                   // look-ahead past the end re-reads the last step
-        const int ks = ks0 + 4 * i;
+        const int ks = ks0 + KS * i;
         const int so = ((ks >> 1) * x.ntiles + (int)blockIdx.y) * 4096 + (ks & 1) * 2048;
         hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
         lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
 
     // ---- halo of the tile, all channels: fp32 global -> bf16 hi | lo units in LDS
     {
-        const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = x.dw_min;
+        const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = ow0 * p.sa_w + x.dw_min;
         constexpr int UB = 6;                                       // units (2 x 16 bytes) per thread and round
         for (int base = 0; base < x.units; base += 256 * UB) {
             float4 v[UB][2];
@@ -138,9 +149,14 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
     // ---- A-operand addressing: pixel li of the tile, channel unit lh of a step; the tap part comes from lane `tap` of lane_off
     int a_base;
     {
-        const int g = li >> x.slot_shift, pr = li & ((1 << x.slot_shift) - 1);
-        const int tr = pr >> x.tw_shift, tc = pr & ((1 << x.tw_shift) - 1);
-        a_base = ((g * x.HRi + tr * p.sa_h) * x.HC + tc * p.sa_w) * x.PS + lh * 32;
+        if constexpr (TILE) {
+            const int tr = 2 * wave + (li >> 4), tc = li & 15;            // this wave's two rows of the 8 x 16 tile
+            a_base = ((tr * p.sa_h) * x.HC + tc * p.sa_w) * x.PS + lh * 32;
+        } else {
+            const int g = li >> x.slot_shift, pr = li & ((1 << x.slot_shift) - 1);
+            const int tr = pr >> x.tw_shift, tc = pr & ((1 << x.tw_shift) - 1);
+            a_base = ((g * x.HRi + tr * p.sa_h) * x.HC + tc * p.sa_w) * x.PS + lh * 32;
+        }
     }
     int lane_off;
     {
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
         lane_off = ((tap.dh - x.dh_min) * x.HC + (tap.dw - x.dw_min)) * x.PS;
     }
     auto step_off = [&](int i) {                                  // LDS byte offset (tap + channel group) of step i of this wave
-        const int ks = ks0 + 4 * i;
+        const int ks = ks0 + KS * i;
         const int t = (int)__umulhi((unsigned)ks, x.inv_nk16);
         return __builtin_amdgcn_readlane(lane_off, t) + (ks - t * x.nk16) * 64;
     };
@@ -180,12 +196,27 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
     };
     sc_chain(step, std::make_integer_sequence<int, SC_MAXSTEPS>{});
 
-    // ---- the four waves' partial tiles: exchanged through LDS, added in the order wave 0, 1, 2, 3
-    __syncthreads();                                                // every wave is past its last halo read
-    float* const xch = reinterpret_cast<float*>(lds);
     const int col = n0 + li;
     const float bias = (p.bias && col < p.Cc) ? p.bias[col] : 0.f;
     const int phh = ph / p.so_w, phw = ph % p.so_w;
+    if constexpr (TILE) {
+        // every wave holds the finished sums of its own 32 pixels
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int tr = 2 * wave + (q >> 4), tc = q & 15;
+            if (col < p.Cc) {
+                const int64_t pix = (int64_t)(n * p.Hc + (oh0 + tr) * p.so_h + phh) * p.Wc + (ow0 + tc) * p.so_w + phw;
+                float o = act_apply(acc[r] + bias, p.act, p.leak);
+                if (p.gact != MV3D_ACT_NONE) o *= act_grad_from_out(p.gref[pix * p.g_ld + col], p.gact, p.gleak);
+                p.Out[pix * p.c_ld + col] = o;
+            }
+        }
+        return;
+    }
+    // ---- the four waves' partial tiles: exchanged through LDS, added in the order wave 0, 1, 2, 3
+    __syncthreads();                                                // every wave is past its last halo read
+    float* const xch = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
@@ -206,6 +237,150 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
     }
 }
 
+// Stride-2 transposed convolution (and the data gradient of a stride-2 convolution), ALL FOUR output phases from one halo:
+// sconv_kernel<true> gave every phase its own workgroup and so staged the halo four times -- the staging (46 KiB per
+// workgroup) weighed as much as the products.  Here the taps of the four phases are one straight-line chain of KSZ^2 x NK16
+// steps (taps are listed phase by phase: 4 + 6 + 6 + 9 for 5 x 5 with SAME padding 1, 4 + 2 + 2 + 1 for 3 x 3; NK16 = channels / 16 -- both
+// template parameters, so every phase boundary is a compile-time position in the chain): at a boundary the wave stores the
+// finished 32 x 32 tile of that phase and clears its ONE accumulator.  The filter ring runs across the boundaries; the saved
+// outputs behind a gradient mask are requested at the START of their phase, so that they are older than the ring's look-ahead
+// loads and have landed long before the phase's epilogue (vmcnt retires in order).
+template <int KSZ> struct PhaseTaps;
+template <> struct PhaseTaps<5> { static constexpr int b[5] = {0, 4, 10, 16, 25}; };
+template <> struct PhaseTaps<3> { static constexpr int b[5] = {0, 4, 6, 8, 9}; };
+
+template <int KSZ, int NK16, bool HAS_G>
+__global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int R = 8;
+    constexpr int NSTEP = KSZ * KSZ * NK16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int b = blockIdx.x;
+    const int tw_i = b % x.tiles_w; b /= x.tiles_w;
+    const int th_i = b % x.tiles_h;
+    const int n = b / x.tiles_h;
+    const int oh0 = th_i * 8, ow0 = tw_i * 16;
+    const int n0 = blockIdx.y * 32;
+
+    uint4 rhi[R], rlo[R];
+    const int wf_bytes = (NSTEP >> 1) * x.ntiles * 4096;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Wf), 0, wf_bytes, 0x00020000);
+    const int wlane = lane * 16;
+    auto load_b = [&](uint4& hi, uint4& lo, int ks) {
+        ks = ks < NSTEP ? ks : NSTEP - 1;
+        const int so = ((ks >> 1) * x.ntiles + (int)blockIdx.y) * 4096 + (ks & 1) * 2048;
+        hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+        lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
+    };
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u) load_b(rhi[u], rlo[u], u);
+
+    // ---- halo of the tile, all channels: fp32 global -> bf16 hi | lo units in LDS
+    {
+        const int ih0 = oh0 + x.dh_min, iw0 = ow0 + x.dw_min;
+        constexpr int UB = 6;
+        for (int base = 0; base < x.units; base += 256 * UB) {
+            float4 v[UB][2];
+            int lofs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int pix = (int)__umulhi((unsigned)idx, x.inv_c8), cu = idx - pix * x.c8;
+                const int hr = (int)__umulhi((unsigned)pix, x.inv_hc), hc = pix - hr * x.HC;
+                const int ih = ih0 + hr, iw = iw0 + hc;
+                const bool ok = idx < x.units && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+                const float* src = ok ? p.A + (int64_t)((n * p.Ha + ih) * p.Wa + iw) * p.a_ld + cu * 8 : p.A;
+                const float4 t0 = reinterpret_cast<const float4*>(src)[0], t1 = reinterpret_cast<const float4*>(src)[1];
+                v[u][0] = ok ? t0 : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u][1] = ok ? t1 : make_float4(0.f, 0.f, 0.f, 0.f);
+                lofs[u] = idx < x.units ? pix * x.PS + cu * 32 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (lofs[u] >= 0) {
+                    uint4 hi, lo;
+                    ssplit8(v[u][0], v[u][1], hi, lo);
+                    *reinterpret_cast<uint4*>(lds + lofs[u]) = hi;
+                    *reinterpret_cast<uint4*>(lds + lofs[u] + 16) = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int tr0 = 2 * wave + (li >> 4), tc0 = li & 15;                  // this lane's pixel of the 8 x 16 tile (A operand)
+    const int a_base = (tr0 * x.HC + tc0) * x.PS + lh * 32;
+    int lane_off;
+    {
+        const IgemmTap tap = p.taps[lane < KSZ * KSZ ? lane : 0];
+        lane_off = ((tap.dh - x.dh_min) * x.HC + (tap.dw - x.dw_min)) * x.PS;
+    }
+    f32x16 acc;
+    uint4 ab[2][2];
+    auto read_a = [&](int buf, int ks) {
+        const unsigned char* ap = lds + a_base + __builtin_amdgcn_readlane(lane_off, ks / NK16) + (ks % NK16) * 64;
+        ab[buf][0] = *reinterpret_cast<const uint4*>(ap);
+        ab[buf][1] = *reinterpret_cast<const uint4*>(ap + 16);
+    };
+    const int col = n0 + li;
+    const float bias = (p.bias && col < p.Cc) ? p.bias[col] : 0.f;
+    const float c1 = p.act == MV3D_ACT_NONE ? 1.f : (p.act == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.leak) : 0.5f);
+    const float c2 = p.act == MV3D_ACT_NONE ? 0.f : (p.act == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.leak) : 0.5f);
+    const bool is_relu = p.act == MV3D_ACT_RELU;
+    const float g1 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.gleak) : 0.5f;
+    const float g2 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.gleak) : 0.5f;
+    const bool g_relu = p.gact == MV3D_ACT_RELU;
+    // output pixel of accumulator register r of phase (phh, phw), minus the lane-independent part
+    auto out_pix = [&](int r, int phh, int phw) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int tr = 2 * wave + (q >> 4), tc = q & 15;
+        return ((n * p.Hc + (oh0 + tr) * 2 + phh) * p.Wc + (ow0 + tc) * 2 + phw);
+    };
+    float gm[16];
+    read_a(0, 0);
+    auto step = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int tap = i / NK16;
+        constexpr int ph = tap < PhaseTaps<KSZ>::b[1] ? 0 : (tap < PhaseTaps<KSZ>::b[2] ? 1 : (tap < PhaseTaps<KSZ>::b[3] ? 2 : 3));
+        constexpr bool first = i == PhaseTaps<KSZ>::b[ph] * NK16, last = i + 1 == PhaseTaps<KSZ>::b[ph + 1] * NK16;
+        if constexpr (first) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if constexpr (HAS_G) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gm[r] = col < p.Cc ? p.gref[(int64_t)out_pix(r, ph >> 1, ph & 1) * p.g_ld + col] : 0.f;
+            }
+        }
+        load_b(rhi[(i + R - 1) % R], rlo[(i + R - 1) % R], i + R - 1);
+        if constexpr (i + 1 < NSTEP) read_a((i + 1) & 1, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const sbf16x8 ah = __builtin_bit_cast(sbf16x8, ab[i & 1][0]), al = __builtin_bit_cast(sbf16x8, ab[i & 1][1]);
+        const sbf16x8 bh = __builtin_bit_cast(sbf16x8, rhi[i % R]), bl = __builtin_bit_cast(sbf16x8, rlo[i % R]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        if constexpr (last) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float xv = acc[r] + bias;
+                float y = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
+                y = (is_relu && xv < 0.0f) ? -0.0f : y;
+                if constexpr (HAS_G) {
+                    const float go = gm[r];
+                    const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
+                    y *= g1 + g2 * (go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f));
+                }
+                if (col < p.Cc) p.Out[(int64_t)out_pix(r, ph >> 1, ph & 1) * p.c_ld + col] = y;
+            }
+        }
+        return true;
+    };
+    sc_chain(step, std::make_integer_sequence<int, NSTEP>{});
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static unsigned inv32(int d) { return (unsigned)((((uint64_t)1 << 32) + d - 1) / (uint64_t)d); }
 
@@ -217,7 +392,9 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     const int Hp = p.Hp[0], Wp = p.Wp[0];
     if (nph == 4 && (p.so_h != 2 || p.so_w != 2 || p.Hp[1] != Hp || p.Wp[1] != Wp)) return 1;
     const int ipx = Hp * Wp;
-    if ((ipx & (ipx - 1)) || (Wp & (Wp - 1)) || Wp < 4 || Wp > 32 || ipx < 16 || ipx > 64) return 1;
+    // TILE kernel: 4-phase problems on phase grids of whole 8 x 16 tiles (the small-image form below takes grids up to 64 pixels)
+    const bool tile = nph == 4 && ipx > 64 && Hp % 8 == 0 && Wp % 16 == 0 && p.sa_h == 1 && p.sa_w == 1 && !(disabled_paths() & 134217728);
+    if (!tile && ((ipx & (ipx - 1)) || (Wp & (Wp - 1)) || Wp < 4 || Wp > 32 || ipx < 16 || ipx > 64)) return 1;
     const int ntaps = p.tap_begin[nph];
     if (ntaps < 2 || ntaps > 36) return 1;
     for (int ph = 0; ph < nph; ++ph) if (p.tap_begin[ph + 1] == p.tap_begin[ph]) return 1;
@@ -227,14 +404,16 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
         dw_min = std::min<int>(dw_min, p.taps[t].dw); dw_max = std::max<int>(dw_max, p.taps[t].dw);
     }
     SconvParams x = {};
-    if (ipx == 16) { x.G = 2; x.TH = Hp; x.tiles_h = 1; }
+    x.tiles_w = 1;
+    if (tile) { x.G = 1; x.TH = 8; x.tiles_h = Hp / 8; x.tiles_w = Wp / 16; }
+    else if (ipx == 16) { x.G = 2; x.TH = Hp; x.tiles_h = 1; }
     else { x.G = 1; x.TH = 32 / Wp; x.tiles_h = Hp / x.TH; }
     if (x.TH < 1 || x.TH * x.tiles_h != Hp) return 1;
     x.tw_shift = 0; while ((1 << x.tw_shift) < Wp) ++x.tw_shift;
     x.slot_shift = 0; while ((1 << x.slot_shift) < x.TH * Wp) ++x.slot_shift;
-    if ((x.G << x.slot_shift) != 32) return 1;
+    if (!tile && (x.G << x.slot_shift) != 32) return 1;
     x.HRi = (x.TH - 1) * p.sa_h + (dh_max - dh_min + 1);
-    x.HC = (Wp - 1) * p.sa_w + (dw_max - dw_min + 1);
+    x.HC = ((tile ? 16 : Wp) - 1) * p.sa_w + (dw_max - dw_min + 1);
     x.PS = p.Ka * 4 + 32;
     x.dh_min = dh_min; x.dw_min = dw_min;
     x.nk16 = p.Ka / 16;
@@ -244,25 +423,56 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     x.c8 = p.Ka / 8; x.inv_c8 = inv32(x.c8); x.inv_hc = inv32(x.HC); x.inv_hri = inv32(x.HRi);
     x.units = x.G * x.HRi * x.HC * x.c8;
     if (x.units >= 65536) return 1;                                 // the multiply-high divisions are exact below 2^16
-    for (int ph = 0; ph < nph; ++ph) if (cdiv((p.tap_begin[ph + 1] - p.tap_begin[ph]) * x.nk16, 4) > SC_MAXSTEPS) return 1;
+    for (int ph = 0; ph < nph; ++ph) if (cdiv((p.tap_begin[ph + 1] - p.tap_begin[ph]) * x.nk16, tile ? 1 : 4) > SC_MAXSTEPS) return 1;
     const size_t halo = (size_t)x.G * x.HRi * x.HC * x.PS;
-    const size_t lds = std::max(halo, (size_t)16 * 1024);
-    if (lds > 160 * 1024) return 1;
+    const size_t lds = tile ? halo : std::max(halo, (size_t)16 * 1024);
+    if (lds > 160 * 1024 || (tile && lds > 52 * 1024)) return 1;      // TILE: three workgroups per CU or the generic kernel
     int rc = MV3D_OK;
     const uint4* wf = bconv_get_filter(p, ws, ws_bytes, stream, &x.ntiles, &rc);
     if (!wf) return rc;
-    const dim3 grid(cdiv(p.N, x.G) * x.tiles_h, cdiv(p.Cc, 32), nph);
+    const dim3 grid(cdiv(p.N, x.G) * x.tiles_h * x.tiles_w, cdiv(p.Cc, 32), nph);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (getenv("MV3D_TRACE"))
         fprintf(stderr, "[mv3d] %-22s sconv<%dph> N=%d in %dx%dx%d (stride %d) out %dx%dx%d taps=%d tile %dx%dx%d halo %dx%d lds=%zu grid=%dx%dx%d %.2f GFLOP\n",
                 who, nph, p.N, p.Ha, p.Wa, p.Ka, p.sa_h, p.Hc, p.Wc, p.Cc, ntaps, x.G, x.TH, Wp, x.G * x.HRi, x.HC, lds, grid.x, grid.y, grid.z, flops * 1e-9);
     const IgemmParams pc = p;
-    return dispatch(stream, OpInfo{nph == 4 ? "sconv<4ph,32px,N32>" : "sconv<1ph,32px,N32>", flops, bytes}, [=](hipStream_t s) {
-        sconv_kernel<<<grid, 256, lds, s>>>(pc, x, wf);
+    if (tile && !(disabled_paths() & 268435456) && (ntaps == 25 || ntaps == 9) && (x.nk16 == 2 || x.nk16 == 4) &&
+        p.act != MV3D_ACT_TANH && p.gact != MV3D_ACT_TANH && (p.gact == MV3D_ACT_NONE || p.gref)) {
+        // all four phases from one halo (sconv4_kernel): the tap list must be the phase-by-phase list the kernel is compiled for
+        const int* tb = ntaps == 25 ? PhaseTaps<5>::b : PhaseTaps<3>::b;
+        bool same = true;
+        for (int ph = 0; ph <= 4; ++ph) same = same && p.tap_begin[ph] == tb[ph];
+        if (same) {
+            const dim3 g4(grid.x, grid.y, 1);
+            const bool hg = p.gact != MV3D_ACT_NONE;
+            const int nk = x.nk16;
+            const bool k5 = ntaps == 25;
+            static bool attr4 = false;
+            if (!attr4) {
+#define MV3D_S4_ATTR(K_, N_, G_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv4_kernel<K_, N_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                MV3D_S4_ATTR(5, 2, false); MV3D_S4_ATTR(5, 2, true); MV3D_S4_ATTR(5, 4, false); MV3D_S4_ATTR(5, 4, true);
+                MV3D_S4_ATTR(3, 2, false); MV3D_S4_ATTR(3, 2, true); MV3D_S4_ATTR(3, 4, false); MV3D_S4_ATTR(3, 4, true);
+#undef MV3D_S4_ATTR
+                attr4 = true;
+            }
+            const char* name = intern_label("sconv4<%s,C%d%s>", k5 ? "5x5" : "3x3", nk * 16, hg ? ",gmask" : "");
+            return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
+#define MV3D_S4(K_, N_) do { if (hg) sconv4_kernel<K_, N_, true><<<g4, 256, lds, s>>>(pc, x, wf); else sconv4_kernel<K_, N_, false><<<g4, 256, lds, s>>>(pc, x, wf); } while (0)
+                if (k5) { if (nk == 4) MV3D_S4(5, 4); else MV3D_S4(5, 2); }
+                else { if (nk == 4) MV3D_S4(3, 4); else MV3D_S4(3, 2); }
+#undef MV3D_S4
+                return launched(who);
+            });
+        }
+    }
+    return dispatch(stream, OpInfo{tile ? "sconv<4ph,tile128,N32>" : (nph == 4 ? "sconv<4ph,32px,N32>" : "sconv<1ph,32px,N32>"), flops, bytes}, [=](hipStream_t s) {
+        if (tile) sconv_kernel<true><<<grid, 256, lds, s>>>(pc, x, wf);
+        else sconv_kernel<false><<<grid, 256, lds, s>>>(pc, x, wf);
         return launched(who);
     });
 }

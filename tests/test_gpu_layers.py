@@ -324,6 +324,19 @@ def test_split_k_small_image_rung_at_batch_64():
         L().set_diagnostics(old)
 
 
+@pytest.mark.parametrize("mask", [268435456, 134217728])
+def test_stride2_transposed_conv_rungs_at_batch_64(mask):
+    """the stride-2 transposed convolutions d1 / d2 (and the data gradients of e1 / e2) on the rungs behind sconv4:
+    268435456 = one output phase per workgroup (sconv<4ph,tile128>), 134217728 = the fused 4-phase bconv kernel of round 1"""
+    old = L().set_diagnostics(mask)
+    try:
+        run_conv_case(LC.APPFLOW_B64[14])          # d1
+        run_conv_case(LC.APPFLOW_B64[12])          # d2
+        run_conv_case(LC.APPFLOW_B64[2])           # e1 (its data gradient is the 4-phase direction)
+    finally:
+        L().set_diagnostics(old)
+
+
 def test_per_item_thin_input_rung_at_batch_64():
     """diagnostics 33554432 | 67108864: the 3- / 2-channel input layers on the kernels the row-band kernels of thin.hip
     replaced (smallc_b3s / smallc_b3 per-item forward, thin_filtgrad on the vector ALUs) stay fallback rungs and stay correct
