@@ -365,7 +365,7 @@ def main():
                                 "fp32-MFMA kernels); activations, loss, resampler, Adam and all stored tensors fp32",
                    # recorded forward + reverse launches, then: fused step = Adam of the fc biases + its record's advance, the remaining
                    # Adam launch + advance (4); otherwise one Adam launch per bucket + 2 advances (data parallel: + the collectives)
-                   "launches_per_step": g.n_launch_fwd + lib.plan_size(bwd_plan) + (4 if bwd_plan is not g.plan_bwd else len([b for b in g.grad_buckets if b[2] > b[1]]) + 2),
+                   "launches_per_step": g.n_launch_fwd + lib.plan_size(bwd_plan) + ((3 if getattr(g, '_finalized_in_plan', False) else 4) if bwd_plan is not g.plan_bwd else len([b for b in g.grad_buckets if b[2] > b[1]]) + 2),
                    "optimiser": ("Adam of the four large fc matrices (97 % of the parameters) fused into their filter-gradient kernels "
                                  "(mv3d_fc_wgrad_adam) and left running under the next step's encoder, one launch for the rest") if bwd_plan is not g.plan_bwd else "bucketed Adam launches"},
         "loss": round(loss, 6),

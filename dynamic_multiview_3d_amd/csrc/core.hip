@@ -25,6 +25,7 @@ struct mv3d_plan {
     std::vector<hipEvent_t> pool;   // 2 events per op per profiled run, collected in bulk
     size_t used = 0;
     hipEvent_t fork[MV3D_MAX_SIDE] = {}, join[MV3D_MAX_SIDE] = {};      // stream dependencies of multi-stream runs
+    bool pass_open = false;         // a profiled pass has been started by a range and not yet closed by the range that ends at the last op
 };
 
 namespace mv3d {
@@ -183,6 +184,13 @@ int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, vo
         if (hipEventCreate(&e) != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_plan_run: hipEventCreate failed");
         p->pool.push_back(e);
     }
+    if (!p->pass_open) {
+        // a pass that starts behind op 0 (the caller left the first launches out): their events are recorded back to back, so
+        // that the collection finds a (zero) duration instead of the stale events of an earlier pass
+        for (int i = 0; i < begin; ++i)
+            if (p->ops[i].selected) { (void)hipEventRecord(p->pool[p->used + 2 * i], s); (void)hipEventRecord(p->pool[p->used + 2 * i + 1], s); }
+        p->pass_open = true;
+    }
     for (int i = begin; i < end; ++i) {
         if (p->ops[i].side == held) continue;
         const bool sel = p->ops[i].selected;
@@ -193,7 +201,7 @@ int mv3d_plan_run_range_multi(mv3d_plan* p, int begin, int end, void* stream, vo
         if (rc != MV3D_OK) return rc;
     }
     join();
-    if (end == n) p->used = need;
+    if (end == n) { p->used = need; p->pass_open = false; }
     return MV3D_OK;
 }
 
@@ -247,6 +255,7 @@ int mv3d_plan_profile_collect(mv3d_plan* p) {
             }
         }
     p->used = 0;
+    (void)hipGetLastError();      // an unrecorded event pair (held side class) is not an error of the next launch
     return MV3D_OK;
 }
 
