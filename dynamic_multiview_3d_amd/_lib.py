@@ -71,6 +71,11 @@ STATUS_FUNCS = {
     "mv3d_comm_allreduce_sum": [_vp, _vp, _i64, _vp],
     "mv3d_comm_reduce_scatter_sum": [_vp, _vp, _vp, _i64, _vp],
     "mv3d_comm_allgather": [_vp, _vp, _vp, _i64, _vp],
+    "mv3d_ipc_export": [_vp, _vp, C.POINTER(_i64)],
+    "mv3d_ipc_open": [_vp, C.POINTER(_vp)],
+    "mv3d_ipc_close": [_vp],
+    "mv3d_mesh_reduce_sum": [C.POINTER(_vp), _i, _vp, _i64, _vp],
+    "mv3d_mesh_copy": [_vp, _vp, _i64, _vp],
     "mv3d_filter_cache_bind": [_G, _i, _vp, _vp, _sz],
     "mv3d_filter_cache_commit": [_vp, _sz, _vp],
     "mv3d_filter_cache_refresh": [_vp],

@@ -433,186 +433,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2)))
 }
 
 
-// Wave-specialised, software-pipelined variant for the layers that carry the FLOPs (single phase, 5x5 / 3x3, 256-pixel
-// tiles x 32 filters).  In bconvu a workgroup's life is a serial chain -- stage the halo (HBM latency), multiply, store
-// -- and only two workgroups fit a CU, so the matrix cores idle for half of it; here a persistent workgroup of 8 waves
-// splits the roles:
-//   * waves 0-3 ("M") only multiply: tap loop of bconvu on halo buffer u&1, filter fragments through their own
-//     register ring (the only global loads they issue, so no s_waitcnt of theirs ever waits for an HBM round trip or
-//     a store), accumulators handed over through a 32 KiB LDS tile at the end of an output tile;
-//   * waves 4-7 ("L") move data: they fetch, split and write the halo of unit u+1 into the other buffer while unit u is
-//     multiplied, and turn the previous tile's accumulators into the output (bias, activation, gradient mask,
-//     16-byte coalesced stores).
-// Two barriers per (tile, chunk) unit: `mid` (L has drained the accumulator tile / M may overwrite it later in the
-// unit) and `end` (next halo complete, this one free).
-template <int NTAPS, int U>
-__global__ __launch_bounds__(512) void bconvw_kernel(const IgemmParams p, const HconvExtra x, const uint4* __restrict__ Wf, int ntiles) {
-    static_assert(NTAPS % U == 0, "ring slots must line up across chunks");
-    constexpr int MT = 2;
-    constexpr int TMID = NTAPS / 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-    const int halo_bytes = x.HR * x.row_bytes;
-    unsigned char* const hbuf0 = lds;
-    float* const obuf = reinterpret_cast<float*>(lds + 2 * halo_bytes);      // [256 pixels][32 filters]
-    const int n0 = blockIdx.y * 32;
-    const int chunks = x.chunks;
-    const int total_tiles = x.n_tiles;
-    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nunits = my_tiles * chunks;
-    auto tile_of = [&](int u) { return (int)blockIdx.x + (u / chunks) * (int)gridDim.x; };
-    auto origin = [&](int tile, int& n, int& oh0, int& ow0) {
-        int bq = tile;
-        const int tw_i = bq % x.tiles_w; bq /= x.tiles_w;
-        const int th_i = bq % x.tiles_h;
-        n = bq / x.tiles_h; oh0 = th_i * x.TH; ow0 = tw_i * x.TW;
-    };
-
-    if (wave < 4) {
-        // ------------------------------------------------------------------ M waves
-        int lane_base[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int pidx = (wave * MT + m) * 32 + li;
-            const int tr = pidx >> x.tw_shift, tc = pidx & (x.TW - 1);
-            lane_base[m] = tr * x.row_bytes + tc * BC_PIXB + lh * 16;
-        }
-        int toff[NTAPS];
-#pragma unroll
-        for (int t = 0; t < NTAPS; ++t)
-            toff[t] = (p.taps[t].dh - x.dh_min) * x.row_bytes + (p.taps[t].dw - x.dw_min) * BC_PIXB;
-        f32x16 acc[MT];
-        struct BSet { uint4 b[2][2]; };
-        BSet ring[U];
-        uint4 a[MT][2][2];
-        const uint4* wf_base = Wf + (int64_t)blockIdx.y * 256;
-        const int64_t tap_stride = (int64_t)chunks * ntiles * 256, chunk_stride = (int64_t)ntiles * 256;
-        auto load_b = [&](BSet& f, int t, int cc) {
-            const uint4* src = wf_base + t * tap_stride + cc * chunk_stride;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) { f.b[s][0] = src[(s * 2) * 64 + lane]; f.b[s][1] = src[(s * 2 + 1) * 64 + lane]; }
-        };
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u) load_b(ring[u], u, 0);
-        __syncthreads();                                             // end barrier of the prologue: halo of unit 0 is in buffer 0
-        for (int u = 0; u < nunits; ++u) {
-            const int cc = u % chunks;
-            const unsigned char* halo = hbuf0 + (u & 1) * halo_bytes;
-            if (cc == 0) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const unsigned char* ap = halo + lane_base[m] + toff[0] + s * 32;
-                    a[m][s][0] = *reinterpret_cast<const uint4*>(ap);
-                    a[m][s][1] = *reinterpret_cast<const uint4*>(ap + 64);
-                }
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                if (t == TMID) __syncthreads();                      // mid barrier
-                {   // look-ahead tap: this chunk, or the first taps of the next unit's chunk
-                    const int tn = t + U - 1;
-                    const int ccn = cc + 1 < chunks ? cc + 1 : 0;
-                    load_b(ring[tn % U], tn < NTAPS ? tn : tn - NTAPS, tn < NTAPS ? cc : ccn);
-                }
-                __builtin_amdgcn_sched_barrier(0);               // keep the look-ahead load here (hipcc sinks it to its first use)
-                const BSet& f = ring[t % U];
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, a[m][s][0]), al = __builtin_bit_cast(bf16x8, a[m][s][1]);
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, f.b[s][0]), bl = __builtin_bit_cast(bf16x8, f.b[s][1]);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[m], 0, 0, 0);
-                        if (t + 1 < NTAPS) {
-                            const unsigned char* ap = halo + lane_base[m] + toff[t + 1 < NTAPS ? t + 1 : t] + s * 32;
-                            a[m][s][0] = *reinterpret_cast<const uint4*>(ap);
-                            a[m][s][1] = *reinterpret_cast<const uint4*>(ap + 64);
-                        }
-                    }
-            }
-            if (cc == chunks - 1) {
-                // accumulators -> LDS tile [pixel][32]: row q = (wave*MT + m)*32 + 8*(r>>2) + (r&3) + 4*lh, column li
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int q = (wave * MT + m) * 32 + 8 * (r >> 2) + (r & 3) + 4 * lh;
-                        obuf[q * 32 + li] = acc[m][r];
-                    }
-            }
-            __syncthreads();                                         // end barrier
-        }
-        __syncthreads();                                             // matches the L waves' final mid barrier
-    } else {
-        // ------------------------------------------------------------------ L waves
-        const int ltid = tid - 256;
-        auto stage = [&](int u) {
-            int n, oh0, ow0;
-            origin(tile_of(u), n, oh0, ow0);
-            bconv_stage_halo<256>(p, x, hbuf0 + (u & 1) * halo_bytes, u % chunks, n, oh0 * p.sa_h + x.dh_min, ow0 * p.sa_w + x.dw_min, ltid);
-        };
-        auto drain = [&](int tile) {
-            int n, oh0, ow0;
-            origin(tile, n, oh0, ow0);
-            const int c4 = ltid & 7;                                 // columns 4*c4 .. +3
-            const int col = n0 + c4 * 4;
-            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias && col + 3 < p.Cc && (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) bias = *reinterpret_cast<const float4*>(p.bias + col);
-            const bool vec_ok = col + 3 < p.Cc && (p.c_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Out) & 15) == 0 &&
-                                (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
-                                (p.gact == MV3D_ACT_NONE || ((p.g_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(p.gref) & 15) == 0));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int q = (ltid >> 3) + 32 * i;                  // pixel of the tile
-                const int ohp = oh0 + (q >> x.tw_shift), owp = ow0 + (q & (x.TW - 1));
-                if (ohp >= p.Hp[0] || owp >= p.Wp[0] || (x.dbg & 16)) continue;
-                const int64_t pix = (int64_t)(n * p.Hc + ohp) * p.Wc + owp;
-                const float4 v = *reinterpret_cast<const float4*>(obuf + q * 32 + c4 * 4);
-                float o[4] = {v.x + bias.x, v.y + bias.y, v.z + bias.z, v.w + bias.w};
-                if (vec_ok) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], p.act, p.leak);
-                    if (p.gact != MV3D_ACT_NONE) {
-                        const float4 gr = *reinterpret_cast<const float4*>(p.gref + pix * p.g_ld + col);
-                        o[0] *= act_grad_from_out(gr.x, p.gact, p.gleak); o[1] *= act_grad_from_out(gr.y, p.gact, p.gleak);
-                        o[2] *= act_grad_from_out(gr.z, p.gact, p.gleak); o[3] *= act_grad_from_out(gr.w, p.gact, p.gleak);
-                    }
-                    *reinterpret_cast<float4*>(p.Out + pix * p.c_ld + col) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < p.Cc) {
-                            float w = act_apply(v.x * (e == 0) + v.y * (e == 1) + v.z * (e == 2) + v.w * (e == 3) + (p.bias ? p.bias[col + e] : 0.f), p.act, p.leak);
-                            if (p.gact != MV3D_ACT_NONE) w *= act_grad_from_out(p.gref[pix * p.g_ld + col + e], p.gact, p.gleak);
-                            p.Out[pix * p.c_ld + col + e] = w;
-                        }
-                }
-            }
-        };
-        if (nunits > 0) stage(0);
-        __syncthreads();                                             // end barrier of the prologue
-        for (int u = 0; u < nunits; ++u) {
-            if (u > 0 && (u % chunks) == 0) drain(tile_of(u - 1));   // the tile finished by unit u-1
-            __syncthreads();                                         // mid barrier: the accumulator tile may be overwritten
-            if (u + 1 < nunits) stage(u + 1);
-            __syncthreads();                                         // end barrier
-        }
-        if (nunits > 0) drain(tile_of(nunits - 1));
-        __syncthreads();
-    }
-}
-
 // LDS row stride: 16 consecutive lanes of a ds_read_b128 group must land on 16 distinct 4-bank slots.
 // With 144-byte pixels that holds inside a tile row; across tile rows it needs the row stride
 // = 0 (mod 256 B) for 16-pixel rows and = 128 (mod 256 B) for 8-pixel rows (MI355X_MICROARCH.md, LDS lane groups).
@@ -725,39 +545,12 @@ static int launch_bconvu_t(const IgemmParams& p, const HconvExtra& x, dim3 grid,
     });
 }
 
-template <int NTAPS, int U>
-static int launch_bconvw_t(const IgemmParams& p, const HconvExtra& x, dim3 grid, const uint4* wf, int ntiles, void* stream,
-                           const char* name, const char* who, double flops, double bytes) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bconvw_kernel<NTAPS, U>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    HconvExtra xp = x;
-    xp.n_tiles = (int)grid.x;
-    name = intern_label("bconvw<%s,256px,N32>", NTAPS == 25 ? "5x5" : "3x3");
-    const size_t lds = 2 * (size_t)bconv_lds_bytes(x) + 256 * 32 * sizeof(float);
-    dim3 pg(std::min<int>((int)grid.x, std::max(1, 256 / (int)grid.y)), grid.y, 1);
-    return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
-        bconvw_kernel<NTAPS, U><<<pg, 512, lds, s>>>(p, xp, wf, ntiles);
-        return launched(who);
-    });
-}
-
 static int launch_bconv_cfg(const IgemmParams& p, const HconvExtra& x, int nph_fused, int MT, int NT, int WAVES, dim3 grid, size_t lds,
                             const uint4* wf, int ntiles, void* stream, const char* name, const char* who, double flops, double bytes) {
 #define MV3D_BC(NPH_, MT_, NT_, W_) launch_bconv_t<NPH_, MT_, NT_, W_>(p, x, grid, lds, wf, ntiles, stream, name, who, flops, bytes)
     const int ntaps_all = p.tap_begin[p.so_h * p.so_w];
     if (WAVES == 8) return launch_cconv(p, x, wf, ntiles, stream, who, flops, bytes);      // pipelined kernel (cconv.hip); planned in hconv.hip
     if (nph_fused == 1 && !x.phase_split && p.so_h == 1 && p.so_w == 1 && (ntaps_all == 25 || ntaps_all == 9) && !(disabled_paths() & 8192)) {
-        // wave-specialised pipeline (two halo buffers + accumulator tile in LDS).  OPT-IN (MV3D_DISABLE bit 15): measured
-        // 3-5 % slower than bconvu on the 64x64x32 layers -- with one multiplying wave per SIMD the tap loop runs at ~2/3
-        // of the rate two co-resident workgroups reach, which eats what the overlap of staging and stores gains.
-        if (MT == 2 && NT == 1 && WAVES == 4 && x.G == 1 && x.ksplit == 1 && grid.z == 1 && (disabled_paths() & 32768) &&
-            2 * (size_t)bconv_lds_bytes(x) + 32768 <= 160 * 1024 && (int)grid.x >= 2 * std::max(1, 256 / (int)grid.y)) {
-            return ntaps_all == 25 ? launch_bconvw_t<25, 5>(p, x, grid, wf, ntiles, stream, name, who, flops, bytes)
-                                   : launch_bconvw_t<9, 3>(p, x, grid, wf, ntiles, stream, name, who, flops, bytes);
-        }
 #define MV3D_BCU(MT_, NT_, W_) (ntaps_all == 25 ? launch_bconvu_t<25, 5, MT_, NT_, W_>(p, x, grid, lds, wf, ntiles, stream, name, who, flops, bytes) \
                                                 : launch_bconvu_t<9, 3, MT_, NT_, W_>(p, x, grid, lds, wf, ntiles, stream, name, who, flops, bytes))
         if (MT == 2 && NT == 1 && WAVES == 4) return MV3D_BCU(2, 1, 4);

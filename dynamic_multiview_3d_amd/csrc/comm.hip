@@ -8,6 +8,7 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <string.h>
+#include <algorithm>
 
 namespace {
 
@@ -114,6 +115,86 @@ int mv3d_comm_allgather(mv3d_comm* c, const void* send, void* recv, int64_t send
     if (!c || !send || !recv || send_count <= 0) return mv3d::fail(MV3D_E_INVAL, "mv3d_comm_allgather: bad arguments");
     int rc = rccl().AllGather(send, recv, (size_t)send_count, kNcclFloat32, c->comm, reinterpret_cast<hipStream_t>(stream));
     return rc == kNcclSuccess ? MV3D_OK : nccl_fail("ncclAllGather", rc);
+}
+
+// ---- mesh-direct exchange: peers' buffers mapped by hipIpc, slices pulled over xGMI point to point ----------------------
+// xGMI is a full mesh of point-to-point links (7 x ~153 GB/s per GPU): a ring collective is bound by ONE link, while a rank that
+// pulls slice r of every peer's buffer directly uses all seven at once.  These entry points are the data plane of that form;
+// the handshake (handles over the control plane, who-reads-what-when) lives with the caller (parallel.MeshComm).
+int mv3d_ipc_export(const void* ptr, void* handle64, int64_t* offset) {
+    if (!ptr || !handle64 || !offset) return mv3d::fail(MV3D_E_INVAL, "mv3d_ipc_export: null argument");
+    void* base = nullptr; size_t size = 0;
+    hipError_t e = hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, const_cast<void*>(ptr));
+    if (e != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_ipc_export: hipMemGetAddressRange: %s", hipGetErrorString(e));
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(h) <= 64, "handle buffer");
+    e = hipIpcGetMemHandle(&h, base);
+    if (e != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_ipc_export: hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    memset(handle64, 0, 64);
+    memcpy(handle64, &h, sizeof(h));
+    *offset = (int64_t)((const char*)ptr - (const char*)base);
+    return MV3D_OK;
+}
+int mv3d_ipc_open(const void* handle64, void** base) {
+    if (!handle64 || !base) return mv3d::fail(MV3D_E_INVAL, "mv3d_ipc_open: null argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    hipError_t e = hipIpcOpenMemHandle(base, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return mv3d::fail(MV3D_E_HIP, "mv3d_ipc_open: hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    return MV3D_OK;
+}
+int mv3d_ipc_close(void* base) {
+    if (!base) return MV3D_OK;
+    hipError_t e = hipIpcCloseMemHandle(base);
+    return e == hipSuccess ? MV3D_OK : mv3d::fail(MV3D_E_HIP, "mv3d_ipc_close: %s", hipGetErrorString(e));
+}
+
+}  // extern "C"
+
+namespace {
+struct MeshSrcs { const float* p[MV3D_MESH_MAX_RANKS]; int n; };
+// dst[i] = srcs[0][i] + srcs[1][i] + ... in rank order: every rank that reduces a slice adds in the same order
+__global__ __launch_bounds__(256) void mesh_reduce_kernel(const MeshSrcs s, float* __restrict__ dst, int64_t count) {
+    const int64_t nvec = count >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        float4 a = reinterpret_cast<const float4*>(s.p[0])[i];
+        for (int r = 1; r < s.n; ++r) {
+            const float4 b = reinterpret_cast<const float4*>(s.p[r])[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(dst)[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const int64_t i = (nvec << 2) + threadIdx.x;
+        float a = s.p[0][i];
+        for (int r = 1; r < s.n; ++r) a += s.p[r][i];
+        dst[i] = a;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int mv3d_mesh_reduce_sum(const void* const* srcs, int nsrc, void* dst, int64_t count, void* stream) {
+    if (!srcs || nsrc < 1 || nsrc > MV3D_MESH_MAX_RANKS || !dst || count <= 0) return mv3d::fail(MV3D_E_INVAL, "mv3d_mesh_reduce_sum: bad arguments (at most %d ranks)", MV3D_MESH_MAX_RANKS);
+    MeshSrcs s = {};
+    s.n = nsrc;
+    for (int r = 0; r < nsrc; ++r) {
+        if (!srcs[r] || ((uintptr_t)srcs[r] & 15)) return mv3d::fail(MV3D_E_INVAL, "mv3d_mesh_reduce_sum: source %d null or not 16-byte aligned", r);
+        s.p[r] = (const float*)srcs[r];
+    }
+    if ((uintptr_t)dst & 15) return mv3d::fail(MV3D_E_INVAL, "mv3d_mesh_reduce_sum: destination not 16-byte aligned");
+    const int blocks = (int)std::min<int64_t>(mv3d::cdiv64(count / 4 + 1, 256), 2048);
+    return mv3d::dispatch(stream, mv3d::OpInfo{"mesh_reduce", 0.0, 4.0 * count * (nsrc + 1)}, [=](hipStream_t st) {
+        mesh_reduce_kernel<<<blocks, 256, 0, st>>>(s, (float*)dst, count);
+        return mv3d::launched("mesh_reduce_kernel");
+    });
+}
+
+int mv3d_mesh_copy(void* dst, const void* src, int64_t count, void* stream) {
+    if (!dst || !src || count <= 0) return mv3d::fail(MV3D_E_INVAL, "mv3d_mesh_copy: bad arguments");
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)count * 4, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream));
+    return e == hipSuccess ? MV3D_OK : mv3d::fail(MV3D_E_HIP, "mv3d_mesh_copy: %s", hipGetErrorString(e));
 }
 
 }  // extern "C"

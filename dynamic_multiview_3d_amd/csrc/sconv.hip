@@ -38,7 +38,7 @@ constexpr int SC_MAXSTEPS = 48;      // reduction steps per wave the straight-li
 struct SconvParams {
     int TH;                 // phase-grid rows of one image slot covered by a tile
     int G;                  // image slots per tile (2: 4 x 4 phase grids, 1 otherwise)
-    int tiles_h, tiles_w;   // row / column tiles per image (tiles_w: TILE kernel only)
+    int tiles_h, tiles_w;   // row / column tiles per image (tiles_w: sconv4 only)
     int tw_shift;           // log2(phase-grid width)
     int slot_shift;         // log2(pixels per image slot) = log2(TH * Wp)
     int HRi, HC, PS;        // halo rows per slot, halo columns, bytes per halo pixel record (4 * Ka + 32)
@@ -65,14 +65,6 @@ __device__ __forceinline__ void ssplit8(const float4& a, const float4& b, uint4&
 template <class F, int... Is>
 __device__ __forceinline__ void sc_chain(F& f, std::integer_sequence<int, Is...>) { (void)(f(std::integral_constant<int, Is>{}) && ...); }
 
-// TILE = false: images of 16 .. 64 phase-grid pixels, 32 pixels per workgroup, reduction split over the four waves (above).
-// TILE = true: larger phase grids (the stride-2 transposed convolutions d1 / d2 and the data gradients of e1 / e2,
-// appearance_flow_model.py:90,92,117,120): a workgroup owns an 8 x 16-pixel tile of one output phase x 32 filters, each wave 32
-// of its pixels (two tile rows) for the WHOLE reduction of the phase (<= 9 taps x 64 channels) -- no exchange; the halo of the
-// tile (10 x 18 pixels x all channels, <= 50 KiB: three workgroups per CU, whose staging and multiplying phases overlap) is
-// staged once, the filter fragments stream from L2.  Replaces the fused 4-phase bconv kernel (93 TFLOP/s: staging, tap loop and
-// stores of a tile in series, two workgroups per CU) for these layers.
-template <bool TILE>
 __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int R = 8;                                  // filter ring: R - 1 steps of look-ahead
@@ -81,20 +73,18 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     int b = blockIdx.x;
-    const int tw_i = TILE ? b % x.tiles_w : 0;
-    if (TILE) b /= x.tiles_w;
     const int th_i = b % x.tiles_h;
     const int n = (b / x.tiles_h) * x.G;                  // first image of the tile
-    const int oh0 = th_i * x.TH, ow0 = tw_i * 16;
+    const int oh0 = th_i * x.TH;
     const int n0 = blockIdx.y * 32;
     const int ph = blockIdx.z;                            // output phase (0 for single-phase problems)
     const int tap_lo = p.tap_begin[ph], tap_hi = p.tap_begin[ph + 1];
 
     // ---- this wave's steps of the reduction: ks = ks0 + wave, + 4, ...  (ks = tap * nk16 + 16-channel group)
-    constexpr int KS = TILE ? 1 : 4;                      // step stride of a wave: all steps (TILE), or every fourth
-    const int ks0 = tap_lo * x.nk16 + (TILE ? 0 : wave);
+    constexpr int KS = 4;                                 // a wave takes every fourth step
+    const int ks0 = tap_lo * x.nk16 + wave;
     const int nsteps = (tap_hi - tap_lo) * x.nk16;
-    const int n_w = TILE ? nsteps : (nsteps > wave ? (nsteps - wave + 3) >> 2 : 0);
+    const int n_w = nsteps > wave ? (nsteps - wave + 3) >> 2 : 0;
     uint4 rhi[R], rlo[R];
     const int wf_bytes = (x.nsteps >> 1) * x.ntiles * 4096;       // nk16 is even: two steps per 32-channel chunk
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Wf), 0, wf_bytes, 0x00020000);
@@ -113,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
 
     // ---- halo of the tile, all channels: fp32 global -> bf16 hi | lo units in LDS
     {
-        const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = ow0 * p.sa_w + x.dw_min;
+        const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = x.dw_min;
         constexpr int UB = 6;                                       // units (2 x 16 bytes) per thread and round
         for (int base = 0; base < x.units; base += 256 * UB) {
             float4 v[UB][2];
@@ -149,14 +139,9 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
     // ---- A-operand addressing: pixel li of the tile, channel unit lh of a step; the tap part comes from lane `tap` of lane_off
     int a_base;
     {
-        if constexpr (TILE) {
-            const int tr = 2 * wave + (li >> 4), tc = li & 15;            // this wave's two rows of the 8 x 16 tile
-            a_base = ((tr * p.sa_h) * x.HC + tc * p.sa_w) * x.PS + lh * 32;
-        } else {
-            const int g = li >> x.slot_shift, pr = li & ((1 << x.slot_shift) - 1);
-            const int tr = pr >> x.tw_shift, tc = pr & ((1 << x.tw_shift) - 1);
-            a_base = ((g * x.HRi + tr * p.sa_h) * x.HC + tc * p.sa_w) * x.PS + lh * 32;
-        }
+        const int g = li >> x.slot_shift, pr = li & ((1 << x.slot_shift) - 1);
+        const int tr = pr >> x.tw_shift, tc = pr & ((1 << x.tw_shift) - 1);
+        a_base = ((g * x.HRi + tr * p.sa_h) * x.HC + tc * p.sa_w) * x.PS + lh * 32;
     }
     int lane_off;
     {
@@ -199,21 +184,6 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
     const int col = n0 + li;
     const float bias = (p.bias && col < p.Cc) ? p.bias[col] : 0.f;
     const int phh = ph / p.so_w, phw = ph % p.so_w;
-    if constexpr (TILE) {
-        // every wave holds the finished sums of its own 32 pixels
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int tr = 2 * wave + (q >> 4), tc = q & 15;
-            if (col < p.Cc) {
-                const int64_t pix = (int64_t)(n * p.Hc + (oh0 + tr) * p.so_h + phh) * p.Wc + (ow0 + tc) * p.so_w + phw;
-                float o = act_apply(acc[r] + bias, p.act, p.leak);
-                if (p.gact != MV3D_ACT_NONE) o *= act_grad_from_out(p.gref[pix * p.g_ld + col], p.gact, p.gleak);
-                p.Out[pix * p.c_ld + col] = o;
-            }
-        }
-        return;
-    }
     // ---- the four waves' partial tiles: exchanged through LDS, added in the order wave 0, 1, 2, 3
     __syncthreads();                                                // every wave is past its last halo read
     float* const xch = reinterpret_cast<float*>(lds);
@@ -238,8 +208,11 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
 }
 
 // Stride-2 transposed convolution (and the data gradient of a stride-2 convolution), ALL FOUR output phases from one halo:
-// sconv_kernel<true> gave every phase its own workgroup and so staged the halo four times -- the staging (46 KiB per
-// workgroup) weighed as much as the products.  Here the taps of the four phases are one straight-line chain of KSZ^2 x NK16
+// a workgroup owns an 8 x 16-pixel tile of the output's phase grid x 32 filters, each wave 32 of its pixels (two tile rows) for the
+// WHOLE reduction -- no exchange; the halo of the tile (10 x 18 pixels x all channels, <= 52 KiB: three workgroups per CU, whose
+// staging and multiplying phases overlap) is staged once, the filter fragments stream from L2.  (A first version gave every
+// phase its own workgroup and so staged the halo four times: the staging weighed as much as the products, 110 TFLOP/s against
+// 177 for the fused form.)  Here the taps of the four phases are one straight-line chain of KSZ^2 x NK16
 // steps (taps are listed phase by phase: 4 + 6 + 6 + 9 for 5 x 5 with SAME padding 1, 4 + 2 + 2 + 1 for 3 x 3; NK16 = channels / 16 -- both
 // template parameters, so every phase boundary is a compile-time position in the chain): at a boundary the wave stores the
 // finished 32 x 32 tile of that phase and clears its ONE accumulator.  The filter ring runs across the boundaries; the saved
@@ -392,7 +365,7 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     const int Hp = p.Hp[0], Wp = p.Wp[0];
     if (nph == 4 && (p.so_h != 2 || p.so_w != 2 || p.Hp[1] != Hp || p.Wp[1] != Wp)) return 1;
     const int ipx = Hp * Wp;
-    // TILE kernel: 4-phase problems on phase grids of whole 8 x 16 tiles (the small-image form below takes grids up to 64 pixels)
+    // sconv4_kernel: 4-phase problems on phase grids of whole 8 x 16 tiles (the small-image form below takes grids up to 64 pixels)
     const bool tile = nph == 4 && ipx > 64 && Hp % 8 == 0 && Wp % 16 == 0 && p.sa_h == 1 && p.sa_w == 1 && !(disabled_paths() & 134217728);
     if (!tile && ((ipx & (ipx - 1)) || (Wp & (Wp - 1)) || Wp < 4 || Wp > 32 || ipx < 16 || ipx > 64)) return 1;
     const int ntaps = p.tap_begin[nph];
@@ -433,15 +406,14 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     const dim3 grid(cdiv(p.N, x.G) * x.tiles_h * x.tiles_w, cdiv(p.Cc, 32), nph);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (getenv("MV3D_TRACE"))
         fprintf(stderr, "[mv3d] %-22s sconv<%dph> N=%d in %dx%dx%d (stride %d) out %dx%dx%d taps=%d tile %dx%dx%d halo %dx%d lds=%zu grid=%dx%dx%d %.2f GFLOP\n",
                 who, nph, p.N, p.Ha, p.Wa, p.Ka, p.sa_h, p.Hc, p.Wc, p.Cc, ntaps, x.G, x.TH, Wp, x.G * x.HRi, x.HC, lds, grid.x, grid.y, grid.z, flops * 1e-9);
     const IgemmParams pc = p;
-    if (tile && !(disabled_paths() & 268435456) && (ntaps == 25 || ntaps == 9) && (x.nk16 == 2 || x.nk16 == 4) &&
+    if (tile && (ntaps == 25 || ntaps == 9) && (x.nk16 == 2 || x.nk16 == 4) &&
         p.act != MV3D_ACT_TANH && p.gact != MV3D_ACT_TANH && (p.gact == MV3D_ACT_NONE || p.gref)) {
         // all four phases from one halo (sconv4_kernel): the tap list must be the phase-by-phase list the kernel is compiled for
         const int* tb = ntaps == 25 ? PhaseTaps<5>::b : PhaseTaps<3>::b;
@@ -470,9 +442,9 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
             });
         }
     }
-    return dispatch(stream, OpInfo{tile ? "sconv<4ph,tile128,N32>" : (nph == 4 ? "sconv<4ph,32px,N32>" : "sconv<1ph,32px,N32>"), flops, bytes}, [=](hipStream_t s) {
-        if (tile) sconv_kernel<true><<<grid, 256, lds, s>>>(pc, x, wf);
-        else sconv_kernel<false><<<grid, 256, lds, s>>>(pc, x, wf);
+    if (tile) return 1;                                             // a tap layout or channel count sconv4 is not compiled for: the generic kernel
+    return dispatch(stream, OpInfo{nph == 4 ? "sconv<4ph,32px,N32>" : "sconv<1ph,32px,N32>", flops, bytes}, [=](hipStream_t s) {
+        sconv_kernel<<<grid, 256, lds, s>>>(pc, x, wf);
         return launched(who);
     });
 }

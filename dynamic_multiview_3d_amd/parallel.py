@@ -13,6 +13,8 @@ import os
 
 import torch
 
+_MESH_MAX = 8        # include/mv3d_hip.h MV3D_MESH_MAX_RANKS
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
@@ -55,6 +57,9 @@ def make_comm(rank, world, backend='rccl', fallback='nccl', _fault=None):
     """Communicator of the data-parallel step.  backend 'rccl': RCCL through the C ABI (csrc/comm.hip), the id travels over the
     control-plane group (gloo); 'nccl': torch.distributed's own RCCL binding; 'gloo': the control-plane group itself (CPU
     rehearsals).  torch.distributed must be initialised.
+
+    'mesh': MeshComm below -- peers' buffers mapped by hipIpc, slices pulled point to point, synchronised over the control
+    plane.
 
     The 'rccl' route either succeeds on EVERY rank or every rank falls back together to `fallback`: the ranks agree on the
     control plane BEFORE each blocking step, so an asymmetric failure never leaves one rank in a collective its peers do not enter --
@@ -108,6 +113,8 @@ def make_comm(rank, world, backend='rccl', fallback='nccl', _fault=None):
         print("[mv3d] rank %d: RCCL through the C ABI unavailable on some rank (step %r, local error %r): all ranks fall back to %s"
               % (rank, stage, err, fallback), file=sys.stderr)
         backend = fallback
+    if backend == 'mesh':
+        return MeshComm(rank, world, control_group())
     if backend == 'nccl':
         return TorchComm(dist.new_group(backend='nccl'))
     return TorchComm(control_group())
@@ -246,3 +253,110 @@ class RcclComm:
         if self._comm:
             self.lib.comm_destroy(self._comm)
             self._comm = None
+
+
+class MeshComm:
+    """Mesh-direct reduce-scatter / all-gather: xGMI is a full mesh of point-to-point links (7 x ~153 GB/s per GPU), so
+    a ring collective is bound by one link while a rank that pulls its slice of every peer's buffer directly uses all of them.
+
+    Every rank maps its peers' flat buffers through hipIpc (mv3d_ipc_*: handles travel over the control plane the first time a
+    buffer is used) and then
+      reduce_scatter: sums slice `rank` of all W buffers, in rank order, into its own buffer (mv3d_mesh_reduce_sum: W - 1 remote
+                      reads of n elements each, one per link);
+      allgather:      pulls the W - 1 other slices from their owners (mv3d_mesh_copy);
+      allreduce:      the two in sequence.
+    Who may read what when is settled on the control plane: a collective starts with a barrier behind a stream synchronize
+    (every rank's producer kernels have finished) and ends with one (every rank's pulls have finished before an owner writes
+    again).  That makes this the REFERENCE form of the mesh exchange -- correct by construction, host-synchronous, and what the
+    two-ranks-on-one-GPU rehearsal (tests/test_gpu_comm.py) holds equal to the gloo / RCCL result; replacing the two barriers by
+    flags in the mapped buffers is the production form once a multi-GPU node is there to measure it on."""
+
+    def __init__(self, rank, world, group=None):
+        import torch.distributed as dist
+        from . import _lib
+        if world > _MESH_MAX:
+            raise ValueError("MeshComm: at most %d ranks" % _MESH_MAX)
+        self.lib = _lib.lib()
+        self.dist, self.group = dist, group
+        self.rank, self.world = rank, world
+        self._maps = {}             # (local base pointer, bytes) -> [pointer of that buffer on rank r, mapped here]
+        self._opened = []
+
+    def _peers(self, buf):
+        """device pointers of `buf` on every rank (the local one for this rank), mapping the peers' on first use (collective)"""
+        import ctypes as C
+        key = (buf.data_ptr(), buf.numel())
+        if key in self._maps:
+            return self._maps[key]
+        handle = C.create_string_buffer(64)
+        off = C.c_int64()
+        self.lib.ipc_export(buf.data_ptr(), handle, C.byref(off))
+        mine = (handle.raw, int(off.value), buf.numel())
+        allh = [None] * self.world
+        self.dist.all_gather_object(allh, mine, group=self.group)
+        ptrs = []
+        for r, (h, o, numel) in enumerate(allh):
+            if numel != buf.numel():
+                raise RuntimeError("MeshComm: rank %d registered %d elements, rank %d %d" % (self.rank, buf.numel(), r, numel))
+            if r == self.rank:
+                ptrs.append(buf.data_ptr())
+            else:
+                base = C.c_void_p()
+                self.lib.ipc_open(C.create_string_buffer(h, 64), C.byref(base))
+                self._opened.append(base.value)
+                ptrs.append(base.value + o)
+        self._maps[key] = ptrs
+        return ptrs
+
+    def _fence(self, stream):
+        """every kernel this rank has issued on `stream` has finished, and every rank has got here"""
+        if stream is not None:
+            torch.cuda.synchronize()
+        self.dist.barrier(group=self.group)
+
+    def reduce_scatter_sum_(self, buf, lo, n, stream):
+        import ctypes as C
+        ptrs = self._peers(buf)
+        self._fence(stream)                                  # all ranks' gradients are final
+        off = 4 * (lo + self.rank * n)
+        srcs = (C.c_void_p * self.world)(*[p + off for p in ptrs])
+        self.lib.mesh_reduce_sum(srcs, self.world, ptrs[self.rank] + off, n, stream)
+        self._fence(stream)                                  # nobody still reads a slice its owner is about to overwrite
+
+    def allgather_(self, buf, lo, n, stream):
+        ptrs = self._peers(buf)
+        self._fence(stream)                                  # every owner's slice is final
+        for d in range(1, self.world):
+            r = (self.rank + d) % self.world                 # every rank starts at a different peer: all links busy at once
+            off = 4 * (lo + r * n)
+            self.lib.mesh_copy(ptrs[self.rank] + off, ptrs[r] + off, n, stream)
+        self._fence(stream)
+
+    def allreduce_sum_(self, buf, lo, n, stream):
+        W = self.world
+        per = -(-n // (4 * W)) * 4                           # slice length: multiple of 4 elements; the last slice may be shorter
+        ptrs = self._peers(buf)
+        import ctypes as C
+        self._fence(stream)
+        a = min(self.rank * per, n)
+        cnt = min(per, n - a)
+        if cnt > 0:
+            off = 4 * (lo + a)
+            srcs = (C.c_void_p * W)(*[p + off for p in ptrs])
+            self.lib.mesh_reduce_sum(srcs, W, ptrs[self.rank] + off, cnt, stream)
+        self._fence(stream)
+        for d in range(1, W):
+            r = (self.rank + d) % W
+            a = min(r * per, n)
+            cnt = min(per, n - a)
+            if cnt > 0:
+                self.lib.mesh_copy(ptrs[self.rank] + 4 * (lo + a), ptrs[r] + 4 * (lo + a), cnt, stream)
+        self._fence(stream)
+
+    def close(self):
+        for b in self._opened:
+            try:
+                self.lib.ipc_close(b)
+            except Exception:       # noqa: BLE001 -- the owner may already be gone at teardown
+                pass
+        self._opened, self._maps = [], {}

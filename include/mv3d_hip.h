@@ -255,6 +255,20 @@ int mv3d_comm_allreduce_sum(mv3d_comm* comm, void* buf, int64_t count, void* str
 int mv3d_comm_reduce_scatter_sum(mv3d_comm* comm, const void* send, void* recv, int64_t recv_count, void* stream);
 int mv3d_comm_allgather(mv3d_comm* comm, const void* send, void* recv, int64_t send_count, void* stream);
 
+/* ---- mesh-direct exchange: xGMI is a full mesh of point-to-point links, so a rank that PULLS its slice of every
+ * peer's gradient buffer directly uses all seven links at once, where a ring collective is bound by one.  mv3d_ipc_export gives
+ * the 64-byte hipIpc handle of the allocation that holds `ptr` and ptr's offset in it; a peer process maps it with
+ * mv3d_ipc_open (base of the allocation; add the offset) and unmaps it with mv3d_ipc_close.  mv3d_mesh_reduce_sum writes
+ * dst[i] = srcs[0][i] + ... + srcs[nsrc-1][i], added in that order (srcs: host array of device pointers, local or mapped;
+ * dst may be one of them); mv3d_mesh_copy is the pull of an updated slice.  Ordering between ranks (nobody reads a buffer its
+ * owner is still writing) is the caller's: parallel.MeshComm does it over the control plane. */
+#define MV3D_MESH_MAX_RANKS 8
+int mv3d_ipc_export(const void* ptr, void* handle64, int64_t* offset);
+int mv3d_ipc_open(const void* handle64, void** base);
+int mv3d_ipc_close(void* base);
+int mv3d_mesh_reduce_sum(const void* const* srcs, int nsrc, void* dst, int64_t count, void* stream);
+int mv3d_mesh_copy(void* dst, const void* src, int64_t count, void* stream);
+
 /* ---- recorded plans: native replay of a fixed launch sequence (the step is static) ----------
  * Between mv3d_plan_begin() and mv3d_plan_end() every mv3d_* op call on this thread is RECORDED
  * (validated, not launched).  mv3d_plan_run() launches the recorded sequence on a stream in one

@@ -324,11 +324,10 @@ def test_split_k_small_image_rung_at_batch_64():
         L().set_diagnostics(old)
 
 
-@pytest.mark.parametrize("mask", [268435456, 134217728])
-def test_stride2_transposed_conv_rungs_at_batch_64(mask):
-    """the stride-2 transposed convolutions d1 / d2 (and the data gradients of e1 / e2) on the rungs behind sconv4:
-    268435456 = one output phase per workgroup (sconv<4ph,tile128>), 134217728 = the fused 4-phase bconv kernel of round 1"""
-    old = L().set_diagnostics(mask)
+def test_stride2_transposed_conv_rung_at_batch_64():
+    """diagnostics 134217728: the stride-2 transposed convolutions d1 / d2 (and the data gradients of e1 / e2) on the fused
+    4-phase bconv kernel of round 1, the rung behind sconv4"""
+    old = L().set_diagnostics(134217728)
     try:
         run_conv_case(LC.APPFLOW_B64[14])          # d1
         run_conv_case(LC.APPFLOW_B64[12])          # d2
