@@ -480,12 +480,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinWgParams p) {
 }
 
 namespace {
-int thin_wg_rb(const mv3d_conv_geom* g) {
-    static int e = -1;
-    if (e < 0) { const char* v = getenv("MV3D_TW_RB"); e = v ? atoi(v) : 4; }
-    if (e == 8 && g->Ho % 8 == 0) return 8;
-    return g->Ho % 4 == 0 ? 4 : 0;
-}
+// band height of the thin filter gradient: four output rows (eight were measured 2 us slower on e0: one workgroup per CU)
+int thin_wg_rb(const mv3d_conv_geom* g) { return g->Ho % 4 == 0 ? 4 : 0; }
 unsigned tinv32(int d) { return (unsigned)((((uint64_t)1 << 32) + d - 1) / (uint64_t)d); }
 }
 

@@ -232,8 +232,7 @@ class ConvNode(Node):
         n, h, w, c = img.shape
         return _lib.conv_geom(n, h, w, c, feat.shape[3], kh, kw, sh, sw, img.ld, feat.ld)
 
-    wg_cus = 0          # CUs of this layer's filter-gradient launch (0 = the library's default; Graph._mark_tail_wgrads)
-    wg_main = False     # filter gradient on the main stream instead of the filter-gradient stream
+    wg_cus = 0          # CUs of this layer's filter-gradient launch (0 = the library's default, mv3d_set_wgrad_cus)
 
     def workspace_bytes(self, g):
         old = g.lib.set_wgrad_cus(self.wg_cus)
@@ -264,9 +263,7 @@ class ConvNode(Node):
         # filter / bias gradients are side work (only Adam reads them): own scratch, may run on the side stream
         kh, kw = self.k[0], self.k[1]
         us = 12.0 + 2.0 * geom.N * geom.Ho * geom.Wo * kh * kw * geom.C * geom.K / 120e6      # rough kernel time, microseconds
-        # wg_main: this layer's filter gradient stays on the MAIN stream (Graph._mark_tail_wgrads: the first layers' filter
-        # gradients are the last launches of the reverse pass, when the data-gradient chain has ended and the main stream idles)
-        ws_side = g.ws_ptr if self.wg_main else g.begin_side(us + 10.0, us if x.requires_grad else 0.0)
+        ws_side = g.begin_side(us + 10.0, us if x.requires_grad else 0.0)
         ws_len = g.ws_bytes
         if g._finalizing:
             # mv3d_grad_finalize_*: the per-slab partial sums stay in THIS layer's region of the arena until the one batched
@@ -281,8 +278,7 @@ class ConvNode(Node):
                                    self.b.grad_ptr if self.b is not None else None, ws_side, ws_len, g.stream)
         finally:
             g.lib.set_wgrad_cus(old_cus)      # process-global override: never leave it set behind a failed call
-        if not self.wg_main:
-            g.end_side()
+        g.end_side()
         self.w.has_grad = True
         if self.b is not None:
             self.b.has_grad = True
@@ -623,16 +619,8 @@ class Graph:
         self.zero_buf = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.zero_ptr = self.zero_buf.data_ptr()
         self.finalized = True       # pointers are valid from here on (workspace queries need them)
-        # The filter gradients of the first layers are the last launches of the reverse pass: the data-gradient chain has ended
-        # by then, so they could spread over the whole chip instead of the half the side stream normally takes (mv3d_set_wgrad_cus).
-        ntail = int(os.environ.get('MV3D_TAIL_WGRADS', '0'))      # measured: no gain at B = 64 (+-0.1 %), so off
-        for n in [n for n in self.nodes if isinstance(n, ConvNode)][:ntail]:
-            n.wg_cus = int(os.environ.get('MV3D_TAIL_WG_CUS', '256'))
-        # MV3D_MAIN_WGRADS: comma-separated indices of conv layers (creation order) whose filter gradient runs on the main stream
-        convs = [n for n in self.nodes if isinstance(n, ConvNode)]
-        for i in [int(t) for t in os.environ.get('MV3D_MAIN_WGRADS', '').split(',') if t.strip()]:
-            if 0 <= i < len(convs):
-                convs[i].wg_main = True
+        # (Measured and dropped, round 2 and again round 3: spreading the LAST filter gradients of the pass -- the first layers' --
+        # over all 256 CUs, or issuing them on the main stream once the data-gradient chain has ended: +-0.3 % on the step.)
         need = 0
         for n in self.nodes:
             if hasattr(n, 'workspace_bytes'):
