@@ -15,8 +15,8 @@ import glob
 import json
 import sys
 
-CONV_FAMILY = ('cconv_kernel', 'cwgrad_kernel', 'bconv', 'wgrad_b3', 'wgrad_tile', 'hconv', 'igemm', 'smallc_', 'thin_', 'filtgrad', 'reduce_slabs',
-               'transpose_filter')
+CONV_FAMILY = ('cconv_kernel', 'cwgrad_kernel', 'bconv', 'sconv', 'wgrad_b3', 'wgrad_tile', 'hconv', 'igemm', 'smallc_', 'thin_', 'filtgrad',
+               'reduce_slabs', 'grad_finalize', 'transpose_filter')
 
 
 def family(k):
