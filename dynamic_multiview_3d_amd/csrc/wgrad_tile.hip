@@ -33,6 +33,7 @@ struct WgTileParams {
     int b3;              // 1: split-bf16 kernel (wgrad_b3_kernel)
     int inv_hc, tpix8_shift;   // ceil(2^20 / HC); log2(TPIX * 8)
     int G, img_shift, HRi, inv_hri;   // small images (4x4 feature maps): a tile is G whole images of 2^img_shift pixels, halos stacked
+    int tsplit;          // split-bf16 kernel: the taps are divided over this many workgroups (grid.z); 1 = all taps in one workgroup
 };
 
 __device__ float4 g_zero16[4];        // 64 bytes of zeros in the code object: source of out-of-image LDS-DMA lanes
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
     // this wave's taps (same k-tile): surplus slots recompute the last real tap into an accumulator never stored
     int tapoff[TPW], item_tap[TPW];
     bool item_ok[TPW];
-    const int tap_lo = (p.ntaps * tg) / tg_per_kt, tap_n = (p.ntaps * (tg + 1)) / tg_per_kt - tap_lo;
+    // taps: tg_per_kt groups per k-tile in a workgroup, times the tap split over workgroups (grid.z)
+    const int tg_total = tg_per_kt * p.tsplit, tgi = (int)blockIdx.z * tg_per_kt + tg;
+    const int tap_lo = (p.ntaps * tgi) / tg_total, tap_n = (p.ntaps * (tgi + 1)) / tg_total - tap_lo;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         int tap = tap_lo + i;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(512) void wgrad_b3_kernel(const WgTileParams p) {
     float4 bsum[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) bsum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool do_bias = p.bias_out != nullptr && ct == 0;
+    const bool do_bias = p.bias_out != nullptr && ct == 0 && blockIdx.z == 0;
     const int n_img4 = halo_pix * 8, n_feat4 = p.TPIX * NKT * 8;
     auto fetch = [&](int tile) {
         int b = tile;
@@ -922,6 +925,16 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     nslab = cdiv(p.ntiles_total, p.tiles_per_slab);
     p.inv_hc = ((1 << 20) + p.HC - 1) / p.HC;
     p.tpix8_shift = p.TPIX == 128 ? 10 : 9;
+    // Tap split (split-bf16 kernels): a workgroup's life on these layers is launch + one or a few tiles + the store of its
+    // partial filter (102 / 204 KB: the longest piece); with the taps divided over two workgroups each stages the same halo
+    // (from L2: the chip is half idle during these launches anyway) and multiplies and stores half -- twice the workgroups,
+    // half the chain.
+    p.tsplit = 1;
+    {
+        static int ts = -1;
+        if (ts < 0) { const char* e = getenv("MV3D_WG_TAPSPLIT"); ts = e ? atoi(e) : 2; }
+        if (b3 && ts == 2) p.tsplit = 2;
+    }
     *out = p;
     *nslab_out = nslab;
     *cfg_out = cfg;
@@ -934,9 +947,16 @@ int wgrad_tile_launch(const mv3d_conv_geom* g, WgTileParams p, int nslab, int cf
     const double flops = 2.0 * g->N * g->Ho * g->Wo * g->kh * g->kw * (double)g->C * g->K;
     const double bytes = 4.0 * ((double)g->N * g->H * g->W * g->C + (double)g->N * g->Ho * g->Wo * g->K + (double)g->kh * g->kw * g->C * g->K);
     const int NKTv = (cfg & 1) ? 2 : 1;
-    dim3 grid(p.ctiles * cdiv(g->K, 32 * NKTv), nslab);
+    dim3 grid(p.ctiles * cdiv(g->K, 32 * NKTv), nslab, p.b3 ? p.tsplit : 1);
     if (p.b3) {
         const bool ni4 = p.HR * p.HC * 8 <= 4 * 512;
+        if (p.tsplit == 2) {         // 25 taps over 2 x 4 groups: at most 4 taps per wave
+            if (cfg == 0) return ni4 ? launch_wgb<4, 1, 4>(p, grid, lds, stream, "wgrad_b3<5x5,K32,taps/2>", who, flops, bytes) : launch_wgb<4, 1, 8>(p, grid, lds, stream, "wgrad_b3<5x5,K32,taps/2>", who, flops, bytes);
+            if (cfg == 1) return ni4 ? launch_wgb<4, 2, 4>(p, grid, lds, stream, "wgrad_b3<5x5,K64,taps/2>", who, flops, bytes) : launch_wgb<4, 2, 8>(p, grid, lds, stream, "wgrad_b3<5x5,K64,taps/2>", who, flops, bytes);
+            // 9 taps over 2 x 2 groups: at most 3 per wave
+            if (cfg == 2) return ni4 ? launch_wgb<3, 1, 4>(p, grid, lds, stream, "wgrad_b3<3x3,K32,taps/2>", who, flops, bytes) : launch_wgb<3, 1, 8>(p, grid, lds, stream, "wgrad_b3<3x3,K32,taps/2>", who, flops, bytes);
+            return ni4 ? launch_wgb<3, 2, 4>(p, grid, lds, stream, "wgrad_b3<3x3,K64,taps/2>", who, flops, bytes) : launch_wgb<3, 2, 8>(p, grid, lds, stream, "wgrad_b3<3x3,K64,taps/2>", who, flops, bytes);
+        }
         switch (cfg) {
             case 0: return ni4 ? launch_wgb<7, 1, 4>(p, grid, lds, stream, "wgrad_b3<5x5,K32>", who, flops, bytes) : launch_wgb<7, 1, 8>(p, grid, lds, stream, "wgrad_b3<5x5,K32>", who, flops, bytes);
             case 1: return ni4 ? launch_wgb<7, 2, 4>(p, grid, lds, stream, "wgrad_b3<5x5,K64>", who, flops, bytes) : launch_wgb<7, 2, 8>(p, grid, lds, stream, "wgrad_b3<5x5,K64>", who, flops, bytes);
