@@ -78,6 +78,7 @@ const uint4* bconv_get_filter(const IgemmParams& p, void* ws, size_t ws_bytes, v
 // sconv.hip: small-image convolution (8 x 8 / 4 x 4 phase grids) with the reduction split inside the workgroup -- no split-K
 // partials, no epilogue launch; returns 1 when the problem is not one of its
 int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes);
+int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes);
 
 // thin.hip: row-band kernel for 1..3-channel image sides (stride 2); returns 1 when not applicable
 int try_smallc_band(const mv3d_conv_geom* g, const IgemmParams& ep, int pt, int pl, const void* img, const void* w, void* feat,

@@ -596,6 +596,10 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
         const int rc = try_sconv(p, ws, ws_bytes, stream, who, flops, bytes);
         if (rc != 1) return rc;
     }
+    if (b3 && nph == 1 && p.sa_h == 2) {                          // stride-2 forward direction, 32 input channels (sconv.hip, s2conv)
+        const int rc = try_s2conv(p, ws, ws_bytes, stream, who, flops, bytes);
+        if (rc != 1) return rc;
+    }
     if (b3) {
         // split-bf16 kernels: prefer 64 pixels x 32..64 columns per wave (operand reuse from registers); two
         // workgroups share a CU, so ask for >= 512 workgroups before settling on a tile size

@@ -50,6 +50,7 @@ struct SconvParams {
     unsigned inv_c8, inv_hc, inv_hri;
     int units;              // G * HRi * HC * c8
     int ntiles;             // 32-filter tiles of the prepared filter
+    int HCp, HCe;           // s2conv: padded halo columns per LDS row, even columns of the halo (the odd ones follow them)
 };
 
 __device__ __forceinline__ void ssplit8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
@@ -354,6 +355,140 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
     sc_chain(step, std::make_integer_sequence<int, NSTEP>{});
 }
 
+// Stride-2 convolution forward (and the data gradient of a stride-2 transposed convolution) on images of whole 8 x 16 output
+// tiles: e1 / e2 forward, d1 / d2 data gradient (appearance_flow_model.py:89-91,121-123 -- 32 input channels each).
+// A workgroup owns an 8 x 16 tile of the OUTPUT x 32 filters, each wave two tile rows for the whole reduction; the input halo
+// of the tile (19 x 35 pixels for 5 x 5) is staged once for all channels with its even and odd COLUMNS apart, so that the 16
+// output pixels of a tile row read 16 consecutive pixel records for every tap (column 2 c + kx is record c + (kx >> 1) of
+// parity kx & 1) and the A-fragment reads stay conflict-free at the record pitch of sconv4; the row pitch is padded until two
+// halo rows (one tile row) are 64 bytes apart modulo the 256-byte bank row, as one halo row is there.  The taps are one
+// straight-line chain of NTAPS x NK16 steps with the filter ring running through it.  (The generic kernel, bconvu, stages a
+// 64-pixel tile per 128-thread workgroup in three rounds of loads and multiplies behind a barrier: 84 - 96 TFLOP/s.)
+template <int NTAPS, int NK16, bool HAS_G>
+__global__ __launch_bounds__(256) void s2conv_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int R = 8;
+    constexpr int NSTEP = NTAPS * NK16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int b = blockIdx.x;
+    const int tw_i = b % x.tiles_w; b /= x.tiles_w;
+    const int th_i = b % x.tiles_h;
+    const int n = b / x.tiles_h;
+    const int oh0 = th_i * 8, ow0 = tw_i * 16;
+    const int n0 = blockIdx.y * 32;
+
+    uint4 rhi[R], rlo[R];
+    const int wf_bytes = (NSTEP >> 1) * x.ntiles * 4096;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Wf), 0, wf_bytes, 0x00020000);
+    const int wlane = lane * 16;
+    auto load_b = [&](uint4& hi, uint4& lo, int ks) {
+        ks = ks < NSTEP ? ks : NSTEP - 1;
+        const int so = ((ks >> 1) * x.ntiles + (int)blockIdx.y) * 4096 + (ks & 1) * 2048;
+        hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
+        lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
+    };
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u) load_b(rhi[u], rlo[u], u);
+
+    // ---- halo of the tile, all channels: fp32 global -> bf16 hi | lo units in LDS, even columns first
+    {
+        const int ih0 = oh0 * 2 + x.dh_min, iw0 = ow0 * 2 + x.dw_min;
+        constexpr int UB = 6;
+        for (int base = 0; base < x.units; base += 256 * UB) {
+            float4 v[UB][2];
+            int lofs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int pix = (int)__umulhi((unsigned)idx, x.inv_c8), cu = idx - pix * x.c8;
+                const int hr = (int)__umulhi((unsigned)pix, x.inv_hc), hc = pix - hr * x.HC;
+                const int ih = ih0 + hr, iw = iw0 + hc;
+                const bool ok = idx < x.units && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+                const float* src = ok ? p.A + (int64_t)((n * p.Ha + ih) * p.Wa + iw) * p.a_ld + cu * 8 : p.A;
+                const float4 t0 = reinterpret_cast<const float4*>(src)[0], t1 = reinterpret_cast<const float4*>(src)[1];
+                v[u][0] = ok ? t0 : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u][1] = ok ? t1 : make_float4(0.f, 0.f, 0.f, 0.f);
+                lofs[u] = idx < x.units ? (hr * x.HCp + (hc & 1) * x.HCe + (hc >> 1)) * x.PS + cu * 32 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (lofs[u] >= 0) {
+                    uint4 hi, lo;
+                    ssplit8(v[u][0], v[u][1], hi, lo);
+                    *reinterpret_cast<uint4*>(lds + lofs[u]) = hi;
+                    *reinterpret_cast<uint4*>(lds + lofs[u] + 16) = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int tr0 = 2 * wave + (li >> 4), tc0 = li & 15;                  // this lane's pixel of the 8 x 16 tile (A operand)
+    const int a_base = (2 * tr0 * x.HCp + tc0) * x.PS + lh * 32;
+    int lane_off;
+    {
+        const IgemmTap tap = p.taps[lane < NTAPS ? lane : 0];
+        const int dc = tap.dw - x.dw_min;
+        lane_off = ((tap.dh - x.dh_min) * x.HCp + (dc & 1) * x.HCe + (dc >> 1)) * x.PS;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    uint4 ab[2][2];
+    auto read_a = [&](int buf, int ks) {
+        const unsigned char* ap = lds + a_base + __builtin_amdgcn_readlane(lane_off, ks / NK16) + (ks % NK16) * 64;
+        ab[buf][0] = *reinterpret_cast<const uint4*>(ap);
+        ab[buf][1] = *reinterpret_cast<const uint4*>(ap + 16);
+    };
+    const int col = n0 + li;
+    const float bias = (p.bias && col < p.Cc) ? p.bias[col] : 0.f;
+    const float c1 = p.act == MV3D_ACT_NONE ? 1.f : (p.act == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.leak) : 0.5f);
+    const float c2 = p.act == MV3D_ACT_NONE ? 0.f : (p.act == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.leak) : 0.5f);
+    const bool is_relu = p.act == MV3D_ACT_RELU;
+    const float g1 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.gleak) : 0.5f;
+    const float g2 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.gleak) : 0.5f;
+    const bool g_relu = p.gact == MV3D_ACT_RELU;
+    auto out_pix = [&](int r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int tr = 2 * wave + (q >> 4), tc = q & 15;
+        return (n * p.Hc + oh0 + tr) * p.Wc + ow0 + tc;
+    };
+    float gm[16];
+    if constexpr (HAS_G) {          // requested before the ring's look-ahead loads of the chain: landed long before the epilogue
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[r] = col < p.Cc ? p.gref[(int64_t)out_pix(r) * p.g_ld + col] : 0.f;
+    }
+    read_a(0, 0);
+    auto step = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        load_b(rhi[(i + R - 1) % R], rlo[(i + R - 1) % R], i + R - 1);
+        if constexpr (i + 1 < NSTEP) read_a((i + 1) & 1, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const sbf16x8 ah = __builtin_bit_cast(sbf16x8, ab[i & 1][0]), al = __builtin_bit_cast(sbf16x8, ab[i & 1][1]);
+        const sbf16x8 bh = __builtin_bit_cast(sbf16x8, rhi[i % R]), bl = __builtin_bit_cast(sbf16x8, rlo[i % R]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        return true;
+    };
+    sc_chain(step, std::make_integer_sequence<int, NSTEP>{});
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float xv = acc[r] + bias;
+        float y = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
+        y = (is_relu && xv < 0.0f) ? -0.0f : y;
+        if constexpr (HAS_G) {
+            const float go = gm[r];
+            const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
+            y *= g1 + g2 * (go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f));
+        }
+        if (col < p.Cc) p.Out[(int64_t)out_pix(r) * p.c_ld + col] = y;
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 static unsigned inv32(int d) { return (unsigned)((((uint64_t)1 << 32) + d - 1) / (uint64_t)d); }
 
@@ -445,6 +580,61 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     if (tile) return 1;                                             // a tap layout or channel count sconv4 is not compiled for: the generic kernel
     return dispatch(stream, OpInfo{nph == 4 ? "sconv<4ph,32px,N32>" : "sconv<1ph,32px,N32>", flops, bytes}, [=](hipStream_t s) {
         sconv_kernel<<<grid, 256, lds, s>>>(pc, x, wf);
+        return launched(who);
+    });
+}
+
+// Stride-2 single-phase problems on output grids of whole 8 x 16 tiles (s2conv_kernel); returns 1 when not one of them.
+int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes) {
+    if (disabled_paths() & 268435456) return 1;
+    if (p.so_h != 1 || p.so_w != 1 || p.sa_h != 2 || p.sa_w != 2) return 1;
+    if (p.fold || p.Ka != 32 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15) || p.Cc < 16) return 1;
+    const int Hp = p.Hp[0], Wp = p.Wp[0];
+    if (Hp % 8 != 0 || Wp % 16 != 0 || Hp * Wp <= 64) return 1;
+    const int ntaps = p.tap_begin[1];
+    if (ntaps != 25 && ntaps != 9) return 1;
+    if (p.act == MV3D_ACT_TANH || p.gact == MV3D_ACT_TANH || (p.gact != MV3D_ACT_NONE && !p.gref)) return 1;
+    int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
+    for (int t = 0; t < ntaps; ++t) {
+        dh_min = std::min<int>(dh_min, p.taps[t].dh); dh_max = std::max<int>(dh_max, p.taps[t].dh);
+        dw_min = std::min<int>(dw_min, p.taps[t].dw); dw_max = std::max<int>(dw_max, p.taps[t].dw);
+    }
+    SconvParams x = {};
+    x.G = 1; x.TH = 8; x.tiles_h = Hp / 8; x.tiles_w = Wp / 16;
+    x.HRi = 7 * 2 + (dh_max - dh_min + 1);
+    x.HC = 15 * 2 + (dw_max - dw_min + 1);
+    x.PS = p.Ka * 4 + 32;
+    x.HCe = (x.HC + 1) / 2;
+    x.HCp = x.HC;
+    while ((2 * x.HCp * x.PS) % 256 != 64) ++x.HCp;                 // one tile row = two halo rows: 64 bytes on in the bank row
+    x.dh_min = dh_min; x.dw_min = dw_min;
+    x.nk16 = p.Ka / 16; x.inv_nk16 = inv32(x.nk16);
+    x.nsteps = ntaps * x.nk16;
+    x.c8 = p.Ka / 8; x.inv_c8 = inv32(x.c8); x.inv_hc = inv32(x.HC); x.inv_hri = inv32(x.HRi);
+    x.units = x.HRi * x.HC * x.c8;
+    if (x.units >= 65536) return 1;
+    const size_t lds = (size_t)x.HRi * x.HCp * x.PS;
+    if (lds > 160 * 1024) return 1;
+    int rc = MV3D_OK;
+    const uint4* wf = bconv_get_filter(p, ws, ws_bytes, stream, &x.ntiles, &rc);
+    if (!wf) return rc;
+    const dim3 grid(p.N * x.tiles_h * x.tiles_w, cdiv(p.Cc, 32), 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+#define MV3D_S2_ATTR(T_, G_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s2conv_kernel<T_, 2, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        MV3D_S2_ATTR(25, false); MV3D_S2_ATTR(25, true); MV3D_S2_ATTR(9, false); MV3D_S2_ATTR(9, true);
+#undef MV3D_S2_ATTR
+        attr_set = true;
+    }
+    if (getenv("MV3D_TRACE"))
+        fprintf(stderr, "[mv3d] %-22s s2conv N=%d in %dx%dx%d out %dx%dx%d taps=%d halo %dx%d (pitch %d) lds=%zu grid=%dx%d %.2f GFLOP\n",
+                who, p.N, p.Ha, p.Wa, p.Ka, p.Hc, p.Wc, p.Cc, ntaps, x.HRi, x.HC, x.HCp, lds, grid.x, grid.y, flops * 1e-9);
+    const IgemmParams pc = p;
+    const bool hg = p.gact != MV3D_ACT_NONE, k5 = ntaps == 25;
+    const char* name = intern_label("s2conv<%s,C32%s>", k5 ? "5x5" : "3x3", hg ? ",gmask" : "");
+    return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
+        if (k5) { if (hg) s2conv_kernel<25, 2, true><<<grid, 256, lds, s>>>(pc, x, wf); else s2conv_kernel<25, 2, false><<<grid, 256, lds, s>>>(pc, x, wf); }
+        else { if (hg) s2conv_kernel<9, 2, true><<<grid, 256, lds, s>>>(pc, x, wf); else s2conv_kernel<9, 2, false><<<grid, 256, lds, s>>>(pc, x, wf); }
         return launched(who);
     });
 }

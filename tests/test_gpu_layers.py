@@ -336,6 +336,17 @@ def test_stride2_transposed_conv_rung_at_batch_64():
         L().set_diagnostics(old)
 
 
+def test_stride2_forward_conv_rung_at_batch_64():
+    """diagnostics 268435456: the stride-2 convolutions e1 / e2 (and the data gradients of d1 / d2) on the unrolled 64-pixel
+    kernel (bconvu), the rung behind s2conv"""
+    old = L().set_diagnostics(268435456)
+    try:
+        for i in (2, 4, 12, 14):          # e1, e2, d2, d1
+            run_conv_case(LC.APPFLOW_B64[i])
+    finally:
+        L().set_diagnostics(old)
+
+
 def test_per_item_thin_input_rung_at_batch_64():
     """diagnostics 33554432 | 67108864: the 3- / 2-channel input layers on the kernels the row-band kernels of thin.hip
     replaced (smallc_b3s / smallc_b3 per-item forward, thin_filtgrad on the vector ALUs) stay fallback rungs and stay correct
