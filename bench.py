@@ -47,7 +47,7 @@ def is_split_bf16(label):
 
 # conv / deconv family: forward, data-gradient and filter-gradient kernels of conv2d_msra / deconv2d_msra
 # (tf_utils.py:70-98) plus the launches that only exist to serve them (mv3d_plan_profile_select pattern syntax)
-CONV_FAMILY = ('cconv*|cwgrad*|bconv*|sconv*|wgrad_b3*|wgrad_tile*|hconv*|igemm*|smallc_*|thin_*|filtgrad*|reduce_slabs|grad_finalize*|transpose_filter')
+CONV_FAMILY = ('cconv*|cwgrad*|bconv*|sconv*|s2conv*|wgrad_b3*|wgrad_tile*|hconv*|igemm*|smallc_*|thin_*|filtgrad*|reduce_slabs|grad_finalize*|transpose_filter')
 
 
 def in_conv_family(label):

@@ -355,38 +355,44 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
     sc_chain(step, std::make_integer_sequence<int, NSTEP>{});
 }
 
-// Stride-2 convolution forward (and the data gradient of a stride-2 transposed convolution) on images of whole 8 x 16 output
+// Stride-2 convolution forward (and the data gradient of a stride-2 transposed convolution) on images of whole 4 x 16 output
 // tiles: e1 / e2 forward, d1 / d2 data gradient (appearance_flow_model.py:89-91,121-123 -- 32 input channels each).
-// A workgroup owns an 8 x 16 tile of the OUTPUT x 32 filters, each wave two tile rows for the whole reduction; the input halo
-// of the tile (19 x 35 pixels for 5 x 5) is staged once for all channels with its even and odd COLUMNS apart, so that the 16
-// output pixels of a tile row read 16 consecutive pixel records for every tap (column 2 c + kx is record c + (kx >> 1) of
-// parity kx & 1) and the A-fragment reads stay conflict-free at the record pitch of sconv4; the row pitch is padded until two
-// halo rows (one tile row) are 64 bytes apart modulo the 256-byte bank row, as one halo row is there.  The taps are one
-// straight-line chain of NTAPS x NK16 steps with the filter ring running through it.  (The generic kernel, bconvu, stages a
+// A workgroup owns a 4 x 16 tile of the OUTPUT; the input halo of the tile (11 x 35 pixels for 5 x 5) is staged once for all
+// channels in ONE round of loads, with its even and odd COLUMNS apart, so that the 16 output pixels of a tile row read 16
+// consecutive pixel records for every tap (column 2 c + kx is record c + (kx >> 1) of parity kx & 1) and the A-fragment
+// reads stay conflict-free at the record pitch of sconv4; the row pitch is padded until two halo rows (one tile row) are 64
+// bytes apart modulo the 256-byte bank row, as one halo row is there.  64 KiB of LDS: two workgroups per CU, one staging or
+// storing while the other multiplies.  Waves 0 / 1 own the two 32-pixel halves of the tile, and so do waves 2 / 3, for
+//   KSPLIT = false: the second 32-filter tile (64 filters per workgroup, whole reduction per wave);
+//   KSPLIT = true:  the second 16-channel half of every tap (32 filters per workgroup; the pair's partial tiles meet in LDS,
+//                   channels 0-15 + channels 16-31, and each wave finishes eight of the sixteen accumulator registers).
+// The taps are one straight-line chain with the filter ring running through it.  (The generic kernel, bconvu, stages a
 // 64-pixel tile per 128-thread workgroup in three rounds of loads and multiplies behind a barrier: 84 - 96 TFLOP/s.)
-template <int NTAPS, int NK16, bool HAS_G>
-__global__ __launch_bounds__(256) void s2conv_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
+template <int NTAPS, bool KSPLIT, bool HAS_G>
+__global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int R = 8;
-    constexpr int NSTEP = NTAPS * NK16;
+    constexpr int NSTEP = KSPLIT ? NTAPS : NTAPS * 2;               // this wave's steps
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    const int pg = wave & 1, half = wave >> 1;                      // pixel group; filter tile (or channel half) of this wave
     int b = blockIdx.x;
     const int tw_i = b % x.tiles_w; b /= x.tiles_w;
     const int th_i = b % x.tiles_h;
     const int n = b / x.tiles_h;
-    const int oh0 = th_i * 8, ow0 = tw_i * 16;
-    const int n0 = blockIdx.y * 32;
+    const int oh0 = th_i * 4, ow0 = tw_i * 16;
+    const int ytile = KSPLIT ? (int)blockIdx.y : (int)blockIdx.y * 2 + half;
+    const int n0 = ytile * 32;
 
     uint4 rhi[R], rlo[R];
-    const int wf_bytes = (NSTEP >> 1) * x.ntiles * 4096;
+    const int wf_bytes = NTAPS * x.ntiles * 4096;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Wf), 0, wf_bytes, 0x00020000);
-    const int wlane = lane * 16;
-    auto load_b = [&](uint4& hi, uint4& lo, int ks) {
-        ks = ks < NSTEP ? ks : NSTEP - 1;
-        const int so = ((ks >> 1) * x.ntiles + (int)blockIdx.y) * 4096 + (ks & 1) * 2048;
+    const int wlane = lane * 16 + (KSPLIT ? half * 2048 : 0);
+    auto load_b = [&](uint4& hi, uint4& lo, int i) {               // step i of this wave
+        i = i < NSTEP ? i : NSTEP - 1;
+        const int so = KSPLIT ? (i * x.ntiles + ytile) * 4096 : ((i >> 1) * x.ntiles + ytile) * 4096 + (i & 1) * 2048;
         hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
         lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
     };
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void s2conv_kernel(const IgemmParams p, const 
     // ---- halo of the tile, all channels: fp32 global -> bf16 hi | lo units in LDS, even columns first
     {
         const int ih0 = oh0 * 2 + x.dh_min, iw0 = ow0 * 2 + x.dw_min;
-        constexpr int UB = 6;
+        constexpr int UB = 7;
         for (int base = 0; base < x.units; base += 256 * UB) {
             float4 v[UB][2];
             int lofs[UB];
@@ -426,8 +432,8 @@ __global__ __launch_bounds__(256) void s2conv_kernel(const IgemmParams p, const 
     }
     __syncthreads();
 
-    const int tr0 = 2 * wave + (li >> 4), tc0 = li & 15;                  // this lane's pixel of the 8 x 16 tile (A operand)
-    const int a_base = (2 * tr0 * x.HCp + tc0) * x.PS + lh * 32;
+    const int tr0 = 2 * pg + (li >> 4), tc0 = li & 15;                    // this lane's pixel of the 4 x 16 tile (A operand)
+    const int a_base = (2 * tr0 * x.HCp + tc0) * x.PS + lh * 32 + (KSPLIT ? half * 64 : 0);
     int lane_off;
     {
         const IgemmTap tap = p.taps[lane < NTAPS ? lane : 0];
@@ -438,8 +444,8 @@ __global__ __launch_bounds__(256) void s2conv_kernel(const IgemmParams p, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     uint4 ab[2][2];
-    auto read_a = [&](int buf, int ks) {
-        const unsigned char* ap = lds + a_base + __builtin_amdgcn_readlane(lane_off, ks / NK16) + (ks % NK16) * 64;
+    auto read_a = [&](int buf, int i) {
+        const unsigned char* ap = lds + a_base + __builtin_amdgcn_readlane(lane_off, KSPLIT ? i : i / 2) + (KSPLIT ? 0 : (i % 2) * 64);
         ab[buf][0] = *reinterpret_cast<const uint4*>(ap);
         ab[buf][1] = *reinterpret_cast<const uint4*>(ap + 16);
     };
@@ -453,13 +459,16 @@ __global__ __launch_bounds__(256) void s2conv_kernel(const IgemmParams p, const 
     const bool g_relu = p.gact == MV3D_ACT_RELU;
     auto out_pix = [&](int r) {
         const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int tr = 2 * wave + (q >> 4), tc = q & 15;
+        const int tr = 2 * pg + (q >> 4), tc = q & 15;
         return (n * p.Hc + oh0 + tr) * p.Wc + ow0 + tc;
     };
-    float gm[16];
+    // the accumulator registers this wave finishes: all sixteen, or (KSPLIT) eight -- 0-7 by the pair's first wave, 8-15 by its second
+    constexpr int NFIN = KSPLIT ? 8 : 16;
+    const int rbase = KSPLIT ? half * 8 : 0;
+    float gm[NFIN];
     if constexpr (HAS_G) {          // requested before the ring's look-ahead loads of the chain: landed long before the epilogue
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gm[r] = col < p.Cc ? p.gref[(int64_t)out_pix(r) * p.g_ld + col] : 0.f;
+        for (int j = 0; j < NFIN; ++j) gm[j] = col < p.Cc ? p.gref[(int64_t)out_pix(rbase + j) * p.g_ld + col] : 0.f;
     }
     read_a(0, 0);
     auto step = [&](auto ic) {
@@ -475,17 +484,41 @@ __global__ __launch_bounds__(256) void s2conv_kernel(const IgemmParams p, const 
         return true;
     };
     sc_chain(step, std::make_integer_sequence<int, NSTEP>{});
+    float fin[NFIN];
+    if constexpr (KSPLIT) {
+        // the pair's partial tiles: each wave hands over the eight registers the other one finishes; channels 0-15 + channels 16-31
+        __syncthreads();                                            // every wave is past its last halo read
+        float* const xch = reinterpret_cast<float*>(lds);           // [wave][8][64]
+        if (half == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float xv = acc[r] + bias;
-        float y = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
-        y = (is_relu && xv < 0.0f) ? -0.0f : y;
-        if constexpr (HAS_G) {
-            const float go = gm[r];
-            const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
-            y *= g1 + g2 * (go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f));
+            for (int j = 0; j < 8; ++j) xch[(wave * 8 + j) * 64 + lane] = acc[8 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xch[(wave * 8 + j) * 64 + lane] = acc[j];
         }
-        if (col < p.Cc) p.Out[(int64_t)out_pix(r) * p.c_ld + col] = y;
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fin[j] = acc[j] + xch[((wave + 2) * 8 + j) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fin[j] = xch[((wave - 2) * 8 + j) * 64 + lane] + acc[8 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) fin[j] = acc[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NFIN; ++j) {
+        const float xv = fin[j] + bias;
+        float o = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
+        o = (is_relu && xv < 0.0f) ? -0.0f : o;
+        if constexpr (HAS_G) {
+            const float go = gm[j];
+            const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
+            o *= g1 + g2 * (go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f));
+        }
+        if (col < p.Cc) p.Out[(int64_t)out_pix(rbase + j) * p.c_ld + col] = o;
     }
 }
 
@@ -584,13 +617,13 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     });
 }
 
-// Stride-2 single-phase problems on output grids of whole 8 x 16 tiles (s2conv_kernel); returns 1 when not one of them.
+// Stride-2 single-phase problems on output grids of whole 4 x 16 tiles (s2conv_kernel); returns 1 when not one of them.
 int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes) {
     if (disabled_paths() & 268435456) return 1;
     if (p.so_h != 1 || p.so_w != 1 || p.sa_h != 2 || p.sa_w != 2) return 1;
     if (p.fold || p.Ka != 32 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15) || p.Cc < 16) return 1;
     const int Hp = p.Hp[0], Wp = p.Wp[0];
-    if (Hp % 8 != 0 || Wp % 16 != 0 || Hp * Wp <= 64) return 1;
+    if (Hp % 4 != 0 || Wp % 16 != 0 || Hp * Wp <= 64) return 1;
     const int ntaps = p.tap_begin[1];
     if (ntaps != 25 && ntaps != 9) return 1;
     if (p.act == MV3D_ACT_TANH || p.gact == MV3D_ACT_TANH || (p.gact != MV3D_ACT_NONE && !p.gref)) return 1;
@@ -600,8 +633,8 @@ int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, co
         dw_min = std::min<int>(dw_min, p.taps[t].dw); dw_max = std::max<int>(dw_max, p.taps[t].dw);
     }
     SconvParams x = {};
-    x.G = 1; x.TH = 8; x.tiles_h = Hp / 8; x.tiles_w = Wp / 16;
-    x.HRi = 7 * 2 + (dh_max - dh_min + 1);
+    x.G = 1; x.TH = 4; x.tiles_h = Hp / 4; x.tiles_w = Wp / 16;
+    x.HRi = 3 * 2 + (dh_max - dh_min + 1);
     x.HC = 15 * 2 + (dw_max - dw_min + 1);
     x.PS = p.Ka * 4 + 32;
     x.HCe = (x.HC + 1) / 2;
@@ -613,28 +646,37 @@ int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, co
     x.c8 = p.Ka / 8; x.inv_c8 = inv32(x.c8); x.inv_hc = inv32(x.HC); x.inv_hri = inv32(x.HRi);
     x.units = x.HRi * x.HC * x.c8;
     if (x.units >= 65536) return 1;
-    const size_t lds = (size_t)x.HRi * x.HCp * x.PS;
-    if (lds > 160 * 1024) return 1;
+    const size_t lds = std::max((size_t)x.HRi * x.HCp * x.PS, (size_t)8 * 1024);
+    if (lds > 80 * 1024) return 1;
     int rc = MV3D_OK;
     const uint4* wf = bconv_get_filter(p, ws, ws_bytes, stream, &x.ntiles, &rc);
     if (!wf) return rc;
-    const dim3 grid(p.N * x.tiles_h * x.tiles_w, cdiv(p.Cc, 32), 1);
+    // 64 filters per workgroup (a wave pair = two filter tiles) where that leaves two workgroups per CU; otherwise (and for
+    // 32-filter layers) the pair splits the channels
+    static int pair_min = -1;
+    if (pair_min < 0) { const char* e = getenv("MV3D_S2_PAIR_MIN"); pair_min = e ? atoi(e) : 512; }
+    const int tiles = p.N * x.tiles_h * x.tiles_w;
+    const bool ksplit = !(p.Cc % 64 == 0 && tiles * (p.Cc / 64) >= pair_min);
+    const dim3 grid(tiles, ksplit ? cdiv(p.Cc, 32) : p.Cc / 64, 1);
     static bool attr_set = false;
     if (!attr_set) {
-#define MV3D_S2_ATTR(T_, G_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s2conv_kernel<T_, 2, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define MV3D_S2_ATTR(T_, G_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s2conv_kernel<T_, false, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+                                  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s2conv_kernel<T_, true, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); } while (0)
         MV3D_S2_ATTR(25, false); MV3D_S2_ATTR(25, true); MV3D_S2_ATTR(9, false); MV3D_S2_ATTR(9, true);
 #undef MV3D_S2_ATTR
         attr_set = true;
     }
     if (getenv("MV3D_TRACE"))
-        fprintf(stderr, "[mv3d] %-22s s2conv N=%d in %dx%dx%d out %dx%dx%d taps=%d halo %dx%d (pitch %d) lds=%zu grid=%dx%d %.2f GFLOP\n",
-                who, p.N, p.Ha, p.Wa, p.Ka, p.Hc, p.Wc, p.Cc, ntaps, x.HRi, x.HC, x.HCp, lds, grid.x, grid.y, flops * 1e-9);
+        fprintf(stderr, "[mv3d] %-22s s2conv N=%d in %dx%dx%d out %dx%dx%d taps=%d halo %dx%d (pitch %d) lds=%zu grid=%dx%d %s %.2f GFLOP\n",
+                who, p.N, p.Ha, p.Wa, p.Ka, p.Hc, p.Wc, p.Cc, ntaps, x.HRi, x.HC, x.HCp, lds, grid.x, grid.y, ksplit ? "ksplit" : "N64", flops * 1e-9);
     const IgemmParams pc = p;
     const bool hg = p.gact != MV3D_ACT_NONE, k5 = ntaps == 25;
-    const char* name = intern_label("s2conv<%s,C32%s>", k5 ? "5x5" : "3x3", hg ? ",gmask" : "");
+    const char* name = intern_label("s2conv<%s,C32,%s%s>", k5 ? "5x5" : "3x3", ksplit ? "N32" : "N64", hg ? ",gmask" : "");
     return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
-        if (k5) { if (hg) s2conv_kernel<25, 2, true><<<grid, 256, lds, s>>>(pc, x, wf); else s2conv_kernel<25, 2, false><<<grid, 256, lds, s>>>(pc, x, wf); }
-        else { if (hg) s2conv_kernel<9, 2, true><<<grid, 256, lds, s>>>(pc, x, wf); else s2conv_kernel<9, 2, false><<<grid, 256, lds, s>>>(pc, x, wf); }
+#define MV3D_S2(T_, K_) do { if (hg) s2conv_kernel<T_, K_, true><<<grid, 256, lds, s>>>(pc, x, wf); else s2conv_kernel<T_, K_, false><<<grid, 256, lds, s>>>(pc, x, wf); } while (0)
+        if (k5) { if (ksplit) MV3D_S2(25, true); else MV3D_S2(25, false); }
+        else { if (ksplit) MV3D_S2(9, true); else MV3D_S2(9, false); }
+#undef MV3D_S2
         return launched(who);
     });
 }

@@ -15,7 +15,7 @@ import glob
 import json
 import sys
 
-CONV_FAMILY = ('cconv_kernel', 'cwgrad_kernel', 'bconv', 'sconv', 'wgrad_b3', 'wgrad_tile', 'hconv', 'igemm', 'smallc_', 'thin_', 'filtgrad',
+CONV_FAMILY = ('cconv_kernel', 'cwgrad_kernel', 'bconv', 'sconv', 's2conv', 'wgrad_b3', 'wgrad_tile', 'hconv', 'igemm', 'smallc_', 'thin_', 'filtgrad',
                'reduce_slabs', 'grad_finalize', 'transpose_filter')
 
 
