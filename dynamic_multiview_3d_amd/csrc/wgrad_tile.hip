@@ -854,8 +854,9 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     if (disabled_paths() & 2) return false;
     if (g->C < 16 || g->C % 4 != 0 || g->K % 4 != 0 || g->img_ld % 4 != 0 || g->feat_ld % 4 != 0) return false;
     const bool b3_on = !(disabled_paths() & 4096);
-    // 4x4 feature maps (split-bf16 kernel only): a 128-pixel tile is 8 whole images
-    const bool small = b3_on && g->Ho == 4 && g->Wo == 4 && g->N >= 8;
+    // 4 x 4 and 8 x 8 feature maps (split-bf16 kernel only): a 128-pixel tile is 8 / 2 whole images (a 16 x 8 tile on an 8 x 8
+    // map is half padding: twice the staging and twice the products)
+    const bool small = b3_on && ((g->Ho == 4 && g->Wo == 4 && g->N >= 8) || (g->Ho == 8 && g->Wo == 8 && g->N >= 2));
     if (!small && (g->Ho * g->Wo < 64 || g->Wo < 8)) return false;
     const int ntaps = g->kh * g->kw;
     // 8 waves = IW item groups x PH pixel ranges; TPW = items per wave (template)
@@ -878,13 +879,15 @@ bool wgrad_tile_plan(const mv3d_conv_geom* g, WgTileParams* out, int* nslab_out,
     const size_t xchg = (PH > 1) ? (size_t)IW * TPW * 4096 : 0;            // end-of-kernel partial exchange
     p.G = 1; p.img_shift = 7; p.HRi = 0;
     if (small) {
-        for (int G = 8; G >= 4 && best < 0; G >>= 1) {          // 8 images (128 pixels) per tile, 4 when the stride-2 halos are too big
-            const int tpix = G * 16;
+        const int side = g->Ho, ipx = side * side, sshift = side == 4 ? 2 : 3;
+        // 128 pixels of whole images per tile, 64 when the stride-2 halos are too big
+        for (int G = 128 / ipx; G >= std::max(1, 64 / ipx) && best < 0; G >>= 1) {
+            const int tpix = G * ipx;
             if ((tpix >> 4) % PH != 0) continue;
-            const int HRi = 3 * g->sh + g->kh, HC = 3 * g->sw + g->kw, HR = G * HRi;
+            const int HRi = (side - 1) * g->sh + g->kh, HC = (side - 1) * g->sw + g->kw, HR = G * HRi;
             const size_t lds = std::max(2 * (size_t)(((HR * HC + tpix * NKT + 7) / 8) * 1024), xchg);
             if (lds > 160 * 1024 || HR * HC * 8 > 8 * 512) continue;
-            p.G = G; p.img_shift = 4; p.TH = 4; p.TW = 4; p.tw_shift = 2; p.tiles_h = p.tiles_w = 1; p.TPIX = tpix;
+            p.G = G; p.img_shift = 2 * sshift; p.TH = side; p.TW = side; p.tw_shift = sshift; p.tiles_h = p.tiles_w = 1; p.TPIX = tpix;
             p.HRi = HRi; p.HC = HC; p.HR = HR;
             best = 1;
         }
