@@ -596,7 +596,7 @@ int try_hconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
         const int rc = try_sconv(p, ws, ws_bytes, stream, who, flops, bytes);
         if (rc != 1) return rc;
     }
-    if (b3 && nph == 1 && p.sa_h == 2) {                          // stride-2 forward direction, 32 input channels (sconv.hip, s2conv)
+    if (b3 && nph == 1) {                                         // 4 x 16-tile kernel: stride 2 with 32 channels, the small stride-1 layers (sconv.hip, s2conv)
         const int rc = try_s2conv(p, ws, ws_bytes, stream, who, flops, bytes);
         if (rc != 1) return rc;
     }

@@ -368,11 +368,15 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
 //                   channels 0-15 + channels 16-31, and each wave finishes eight of the sixteen accumulator registers).
 // The taps are one straight-line chain with the filter ring running through it.  (The generic kernel, bconvu, stages a
 // 64-pixel tile per 128-thread workgroup in three rounds of loads and multiplies behind a barrier: 84 - 96 TFLOP/s.)
-template <int NTAPS, bool KSPLIT, bool HAS_G>
+// S = 1 (round 3, later): the same kernel without the column split takes the stride-1 layers on 32 x 32 and 16 x 16 maps (e1_0,
+// e2_0, d2_0, d3_0, forward and data gradient) from the pipelined kernel, whose persistent one-workgroup-per-CU pipeline has an
+// 11 k-cycle prologue that layers of one or two stages per CU live in.  NK16 = channels / 16 (2 or 4).
+template <int NTAPS, int S, int NK16, bool KSPLIT, bool HAS_G>
 __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int R = 8;
-    constexpr int NSTEP = KSPLIT ? NTAPS : NTAPS * 2;               // this wave's steps
+    constexpr int KG = KSPLIT ? NK16 / 2 : NK16;                    // 16-channel groups of a tap this wave multiplies
+    constexpr int NSTEP = NTAPS * KG;                               // this wave's steps
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,12 +391,14 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
     const int n0 = ytile * 32;
 
     uint4 rhi[R], rlo[R];
-    const int wf_bytes = NTAPS * x.ntiles * 4096;
+    const int wf_bytes = NTAPS * (NK16 / 2) * x.ntiles * 4096;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Wf), 0, wf_bytes, 0x00020000);
-    const int wlane = lane * 16 + (KSPLIT ? half * 2048 : 0);
-    auto load_b = [&](uint4& hi, uint4& lo, int i) {               // step i of this wave
+    const int wlane = lane * 16;
+    const int kofs = KSPLIT ? half * KG : 0;                        // first 16-channel group of this wave
+    auto load_b = [&](uint4& hi, uint4& lo, int i) {               // step i of this wave: tap i / KG, group kofs + i % KG
         i = i < NSTEP ? i : NSTEP - 1;
-        const int so = KSPLIT ? (i * x.ntiles + ytile) * 4096 : ((i >> 1) * x.ntiles + ytile) * 4096 + (i & 1) * 2048;
+        const int ks = (i / KG) * NK16 + (i % KG) + kofs;
+        const int so = ((ks >> 1) * x.ntiles + ytile) * 4096 + (ks & 1) * 2048;
         hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
         lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
     };
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
 
     // ---- halo of the tile, all channels: fp32 global -> bf16 hi | lo units in LDS, even columns first
     {
-        const int ih0 = oh0 * 2 + x.dh_min, iw0 = ow0 * 2 + x.dw_min;
+        const int ih0 = oh0 * S + x.dh_min, iw0 = ow0 * S + x.dw_min;
         constexpr int UB = 7;
         for (int base = 0; base < x.units; base += 256 * UB) {
             float4 v[UB][2];
@@ -417,7 +423,8 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
                 const float4 t0 = reinterpret_cast<const float4*>(src)[0], t1 = reinterpret_cast<const float4*>(src)[1];
                 v[u][0] = ok ? t0 : make_float4(0.f, 0.f, 0.f, 0.f);
                 v[u][1] = ok ? t1 : make_float4(0.f, 0.f, 0.f, 0.f);
-                lofs[u] = idx < x.units ? (hr * x.HCp + (hc & 1) * x.HCe + (hc >> 1)) * x.PS + cu * 32 : -1;
+                const int cs = S == 2 ? (hc & 1) * x.HCe + (hc >> 1) : hc;
+                lofs[u] = idx < x.units ? (hr * x.HCp + cs) * x.PS + cu * 32 : -1;
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -433,19 +440,19 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
     __syncthreads();
 
     const int tr0 = 2 * pg + (li >> 4), tc0 = li & 15;                    // this lane's pixel of the 4 x 16 tile (A operand)
-    const int a_base = (2 * tr0 * x.HCp + tc0) * x.PS + lh * 32 + (KSPLIT ? half * 64 : 0);
+    const int a_base = (S * tr0 * x.HCp + tc0) * x.PS + lh * 32 + kofs * 64;
     int lane_off;
     {
         const IgemmTap tap = p.taps[lane < NTAPS ? lane : 0];
         const int dc = tap.dw - x.dw_min;
-        lane_off = ((tap.dh - x.dh_min) * x.HCp + (dc & 1) * x.HCe + (dc >> 1)) * x.PS;
+        lane_off = ((tap.dh - x.dh_min) * x.HCp + (S == 2 ? (dc & 1) * x.HCe + (dc >> 1) : dc)) * x.PS;
     }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     uint4 ab[2][2];
     auto read_a = [&](int buf, int i) {
-        const unsigned char* ap = lds + a_base + __builtin_amdgcn_readlane(lane_off, KSPLIT ? i : i / 2) + (KSPLIT ? 0 : (i % 2) * 64);
+        const unsigned char* ap = lds + a_base + __builtin_amdgcn_readlane(lane_off, i / KG) + (i % KG) * 64;
         ab[buf][0] = *reinterpret_cast<const uint4*>(ap);
         ab[buf][1] = *reinterpret_cast<const uint4*>(ap + 16);
     };
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
     sc_chain(step, std::make_integer_sequence<int, NSTEP>{});
     float fin[NFIN];
     if constexpr (KSPLIT) {
-        // the pair's partial tiles: each wave hands over the eight registers the other one finishes; channels 0-15 + channels 16-31
+        // the pair's partial tiles: each wave hands over the eight registers the other one finishes; lower channel half + upper channel half
         __syncthreads();                                            // every wave is past its last halo read
         float* const xch = reinterpret_cast<float*>(lds);           // [wave][8][64]
         if (half == 0) {
@@ -617,29 +624,38 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     });
 }
 
-// Stride-2 single-phase problems on output grids of whole 4 x 16 tiles (s2conv_kernel); returns 1 when not one of them.
+// Single-phase problems on output grids of whole 4 x 16 tiles (s2conv_kernel): stride 2 with 32 channels, stride 1 with 32 or 64
+// channels where the pipelined kernel would run its 8 x 16-tile instance; returns 1 when not one of them.
 int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, const char* who, double flops, double bytes) {
     if (disabled_paths() & 268435456) return 1;
-    if (p.so_h != 1 || p.so_w != 1 || p.sa_h != 2 || p.sa_w != 2) return 1;
-    if (p.fold || p.Ka != 32 || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15) || p.Cc < 16) return 1;
+    if (p.so_h != 1 || p.so_w != 1 || p.sa_h != p.sa_w || (p.sa_h != 1 && p.sa_h != 2)) return 1;
+    const int S = p.sa_h;
+    if (p.fold || (p.Ka != 32 && !(S == 1 && p.Ka == 64)) || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15) || p.Cc < 16) return 1;
     const int Hp = p.Hp[0], Wp = p.Wp[0];
     if (Hp % 4 != 0 || Wp % 16 != 0 || Hp * Wp <= 64) return 1;
     const int ntaps = p.tap_begin[1];
     if (ntaps != 25 && ntaps != 9) return 1;
     if (p.act == MV3D_ACT_TANH || p.gact == MV3D_ACT_TANH || (p.gact != MV3D_ACT_NONE && !p.gref)) return 1;
+    if (S == 1) {
+        // the layers whose 16 x 16 x 32-filter task list is shorter than two per CU (what MV3D_CC_TH8_BELOW sends to cconv's 8 x 16 tiles)
+        static int s1_below = -1;
+        if (s1_below < 0) { const char* e = getenv("MV3D_TC_S1_BELOW"); s1_below = e ? atoi(e) : 512; }
+        if (p.N * cdiv(Hp, 16) * cdiv(Wp, 16) * cdiv(p.Cc, 32) >= s1_below) return 1;
+    }
     int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
     for (int t = 0; t < ntaps; ++t) {
         dh_min = std::min<int>(dh_min, p.taps[t].dh); dh_max = std::max<int>(dh_max, p.taps[t].dh);
         dw_min = std::min<int>(dw_min, p.taps[t].dw); dw_max = std::max<int>(dw_max, p.taps[t].dw);
     }
+    if (ntaps == 25 ? (dh_max - dh_min != 4 || dw_max - dw_min != 4) : (dh_max - dh_min != 2 || dw_max - dw_min != 2)) return 1;
     SconvParams x = {};
     x.G = 1; x.TH = 4; x.tiles_h = Hp / 4; x.tiles_w = Wp / 16;
-    x.HRi = 3 * 2 + (dh_max - dh_min + 1);
-    x.HC = 15 * 2 + (dw_max - dw_min + 1);
+    x.HRi = 3 * S + (dh_max - dh_min + 1);
+    x.HC = 15 * S + (dw_max - dw_min + 1);
     x.PS = p.Ka * 4 + 32;
     x.HCe = (x.HC + 1) / 2;
     x.HCp = x.HC;
-    while ((2 * x.HCp * x.PS) % 256 != 64) ++x.HCp;                 // one tile row = two halo rows: 64 bytes on in the bank row
+    while ((S * x.HCp * x.PS) % 256 != 64) ++x.HCp;                 // one tile row = S halo rows: 64 bytes on in the bank row
     x.dh_min = dh_min; x.dw_min = dw_min;
     x.nk16 = p.Ka / 16; x.inv_nk16 = inv32(x.nk16);
     x.nsteps = ntaps * x.nk16;
@@ -658,25 +674,25 @@ int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, co
     const int tiles = p.N * x.tiles_h * x.tiles_w;
     const bool ksplit = !(p.Cc % 64 == 0 && tiles * (p.Cc / 64) >= pair_min);
     const dim3 grid(tiles, ksplit ? cdiv(p.Cc, 32) : p.Cc / 64, 1);
-    static bool attr_set = false;
-    if (!attr_set) {
-#define MV3D_S2_ATTR(T_, G_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s2conv_kernel<T_, false, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-                                  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&s2conv_kernel<T_, true, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); } while (0)
-        MV3D_S2_ATTR(25, false); MV3D_S2_ATTR(25, true); MV3D_S2_ATTR(9, false); MV3D_S2_ATTR(9, true);
-#undef MV3D_S2_ATTR
-        attr_set = true;
-    }
-    if (getenv("MV3D_TRACE"))
-        fprintf(stderr, "[mv3d] %-22s s2conv N=%d in %dx%dx%d out %dx%dx%d taps=%d halo %dx%d (pitch %d) lds=%zu grid=%dx%d %s %.2f GFLOP\n",
-                who, p.N, p.Ha, p.Wa, p.Ka, p.Hc, p.Wc, p.Cc, ntaps, x.HRi, x.HC, x.HCp, lds, grid.x, grid.y, ksplit ? "ksplit" : "N64", flops * 1e-9);
-    const IgemmParams pc = p;
     const bool hg = p.gact != MV3D_ACT_NONE, k5 = ntaps == 25;
-    const char* name = intern_label("s2conv<%s,C32,%s%s>", k5 ? "5x5" : "3x3", ksplit ? "N32" : "N64", hg ? ",gmask" : "");
+    const int nk = x.nk16;
+    using KernelT = void (*)(const IgemmParams, const SconvParams, const uint4*);
+    KernelT kern = nullptr;
+#define MV3D_S2_PICK(T_, S_, N_) kern = ksplit ? (hg ? &s2conv_kernel<T_, S_, N_, true, true> : &s2conv_kernel<T_, S_, N_, true, false>) \
+                                               : (hg ? &s2conv_kernel<T_, S_, N_, false, true> : &s2conv_kernel<T_, S_, N_, false, false>)
+    if (S == 2) { if (k5) MV3D_S2_PICK(25, 2, 2); else MV3D_S2_PICK(9, 2, 2); }
+    else if (nk == 2) { if (k5) MV3D_S2_PICK(25, 1, 2); else MV3D_S2_PICK(9, 1, 2); }
+    else { if (k5) MV3D_S2_PICK(25, 1, 4); else MV3D_S2_PICK(9, 1, 4); }
+#undef MV3D_S2_PICK
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipGetLastError();            // recording without a device: the attribute call fails and nothing is launched
+    if (getenv("MV3D_TRACE"))
+        fprintf(stderr, "[mv3d] %-22s s2conv N=%d in %dx%dx%d (stride %d) out %dx%dx%d taps=%d halo %dx%d (pitch %d) lds=%zu grid=%dx%d %s %.2f GFLOP\n",
+                who, p.N, p.Ha, p.Wa, p.Ka, S, p.Hc, p.Wc, p.Cc, ntaps, x.HRi, x.HC, x.HCp, lds, grid.x, grid.y, ksplit ? "ksplit" : "N64", flops * 1e-9);
+    const IgemmParams pc = p;
+    const char* name = intern_label("s2conv<%s,s%d,C%d,%s%s>", k5 ? "5x5" : "3x3", S, p.Ka, ksplit ? "N32" : "N64", hg ? ",gmask" : "");
     return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
-#define MV3D_S2(T_, K_) do { if (hg) s2conv_kernel<T_, K_, true><<<grid, 256, lds, s>>>(pc, x, wf); else s2conv_kernel<T_, K_, false><<<grid, 256, lds, s>>>(pc, x, wf); } while (0)
-        if (k5) { if (ksplit) MV3D_S2(25, true); else MV3D_S2(25, false); }
-        else { if (ksplit) MV3D_S2(9, true); else MV3D_S2(9, false); }
-#undef MV3D_S2
+        kern<<<grid, 256, lds, s>>>(pc, x, wf);
         return launched(who);
     });
 }
