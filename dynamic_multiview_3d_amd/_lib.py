@@ -52,6 +52,7 @@ STATUS_FUNCS = {
     "mv3d_warp_resample_bwd": [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "mv3d_warp_resample_loss": [_i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp],
     "mv3d_pixel_loss": [_i64, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp],
+    "mv3d_loss_overwrite_next": [],
     "mv3d_pixel_loss_strided": [_i64, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _f, _vp, _vp, _i, _vp],
     "mv3d_tfrecord_open": [C.c_char_p, _i, C.POINTER(_vp)],
     "mv3d_tfrecord_read": [_vp, _i, _i, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(_vp), C.POINTER(C.c_int)],

@@ -20,13 +20,19 @@ constexpr int LOSS_ROWS = 32, LOSS_MAXB = 1024;
 __device__ unsigned g_loss_part[LOSS_ROWS][LOSS_MAXB];
 __device__ unsigned g_loss_ticket[LOSS_ROWS];
 
+// mv3d_loss_overwrite_next(): the next loss call of this thread STORES its sum instead of adding it to the accumulator -- the
+// first loss term of a recorded step, which then needs no launch that clears the accumulator (flag = bit 8 of the row).
+static thread_local bool g_loss_overwrite = false;
 static int next_loss_row() {
     static std::atomic<unsigned> n{0};
-    return (int)(n.fetch_add(1) % LOSS_ROWS);
+    const int flag = g_loss_overwrite ? 256 : 0;
+    g_loss_overwrite = false;
+    return (int)(n.fetch_add(1) % LOSS_ROWS) | flag;
 }
 
 // every thread of a 256-thread workgroup calls this; thread 0 passes the workgroup's term
-__device__ __forceinline__ void loss_combine(float term, float* loss, int row) {
+__device__ __forceinline__ void loss_combine(float term, float* loss, int row_flag) {
+    const int row = row_flag & 255;
     __shared__ unsigned s_last;
     __shared__ float s_w[4];
     if (threadIdx.x == 0) {
@@ -44,7 +50,8 @@ __device__ __forceinline__ void loss_combine(float term, float* loss, int row) {
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(loss, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+        const float total = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        if (row_flag & 256) *loss = total; else atomicAdd(loss, total);
         __hip_atomic_store(&g_loss_ticket[row], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -713,6 +720,8 @@ int mv3d_group_sum(int64_t groups, int group, int ch, const void* src, int64_t s
         return launched("group_sum_kernel");
     });
 }
+
+int mv3d_loss_overwrite_next(void) { g_loss_overwrite = true; return MV3D_OK; }
 
 // ---- gradient finalisation (see grad_finalize_kernel) -------------------------------------------------------------------------
 int mv3d_grad_finalize_begin(void) {

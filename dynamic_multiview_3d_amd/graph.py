@@ -695,7 +695,11 @@ class Graph:
         lib.plan_begin(self.plan_fwd)
         try:
             lib.filter_cache_refresh(None)      # first launch of the step: convert every conv filter once
-            lib.fill(self.loss_buf.data_ptr(), 1, 0.0, self.stream)      # loss terms accumulate into loss_buf[0]
+            # loss terms accumulate into loss_buf[0]; the first one recorded stores instead (no launch to clear the accumulator)
+            if self.loss_expr is not None and self.loss_expr.terms:
+                lib.loss_overwrite_next()
+            else:
+                lib.fill(self.loss_buf.data_ptr(), 1, 0.0, self.stream)
             self._fwd_first_op = {}
             for n in self.nodes:
                 self._fwd_first_op[id(n)] = lib.plan_size(self.plan_fwd)

@@ -191,6 +191,10 @@ int mv3d_pixel_loss_strided(int64_t pixels, int ch, const void* a, int a_ld, con
                             const void* mask, int mask_ld, int kind, float weight, void* loss_accum, void* grad, int grad_ld,
                             void* stream);
 int mv3d_fill(void* dst, int64_t count, float value, void* stream);
+/* The NEXT loss call of the calling thread (mv3d_pixel_loss*, mv3d_warp_resample_loss) stores its term into loss_accum instead of
+ * adding it: the first term of a recorded step then needs no launch that clears the accumulator (tf.add_n over the terms of
+ * appearance_flow_model.py:127-130 starts from the first one). */
+int mv3d_loss_overwrite_next(void);
 
 /* ---- Adam: tf.train.AdamOptimizer ApplyAdam (appearance_flow_model.py:77) -------
  *   alpha = lr*sqrt(1-beta2_power)/(1-beta1_power);  m += (g-m)(1-b1);  v += (g*g-v)(1-b2);
