@@ -1194,6 +1194,10 @@ static int run_igemm(IgemmParams p, void* ws, size_t ws_bytes, void* stream, con
         if (s2) {
             const int KS = ntaps_all == 25 ? 5 : 3;
             const size_t lds2 = (size_t)KS * KS * p.Cc * p.Ka * sizeof(float);
+            if (p.Ka == 32) {          // matrix-core form (thin.hip)
+                const int hrc = try_thin_head(p, stream, who, flops, bytes);
+                if (hrc != 1) return hrc;
+            }
             if (p.Ka == 32 && !(disabled_paths() & 131072)) {
                 const int HR = KS == 5 ? 18 : 17;
                 // filter rows contiguous along the reduction and 16-byte aligned: read them with scalar loads

@@ -85,6 +85,7 @@ int try_smallc_band(const mv3d_conv_geom* g, const IgemmParams& ep, int pt, int 
                     void* stream, const char* who, double flops, double bytes);
 
 // thin.hip: matrix-core filter gradient of the same layers: slabs (0 = not applicable) and launch (partials [slab][filter] + [slab][K])
+int try_thin_head(const IgemmParams& p, void* stream, const char* who, double flops, double bytes);
 int thin_wgrad_slabs(const mv3d_conv_geom* g);
 int thin_wgrad_launch(const mv3d_conv_geom* g, const void* img, const void* feat, void* part, void* bias_part, void* stream,
                       const char* who, double flops, double bytes);

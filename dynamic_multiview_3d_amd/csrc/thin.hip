@@ -14,6 +14,7 @@
 //     the in-order vmcnt queue only ever holds stores.
 #include "conv_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace mv3d {
 
@@ -218,6 +219,225 @@ __global__ __launch_bounds__(256) void smallc_band_kernel(const BandParams p) {
         tstamp(st, wave, lane, sk);                                        // 5 + i: tile i done (stores issued)
     }
     if (st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tstamp(st, wave, lane, sk); }      // last: stores acknowledged
+}
+
+// thin_head_kernel (feature -> image direction, stride 2, 1..4 image channels, 32 feature channels: the flow / rgb / depth / mask
+// heads, appearance_flow_model.py:125, main_model.py:74-79).  The kernel it replaces (conv.hip thin_deconv_s2_tile_kernel)
+// multiplies on the vector ALUs: 0.84 GFLOP of packed FMAs per launch, 38 us for 42 MB.  Here the products go to the matrix
+// cores as ONE small GEMM per workgroup and the transposed convolution becomes a gather:
+//   T[input pixel][(filter row P, filter column Q, image channel c)] = sum_k x[pixel][k] W[P][Q][c][k]      (N = KS^2 CC <= 128 columns)
+//   out[2 u + a][2 v + b][c] = bias + sum over the (dh, dw) with P = a + PT - 2 dh, Q = b + PT - 2 dw inside the filter of
+//                              T[(u + dh, v + dw)][P][Q][c]
+// A workgroup owns 8 x 16 positions of the input grid: the 10 x 18 halo (x 32 channels) is fetched in one round of loads and
+// split into bf16 hi / lo records in LDS (144-byte pitch), its 6 blocks of 32 pixels are dealt to the four waves, T goes to LDS as
+// fp32 with an odd pitch, and after one barrier a thread adds up the <= 15 T values of each of its output elements in a fixed
+// order (thread = (output row parity, position): its two output pixels x CC channels are 8 CC contiguous bytes, a tile row of 16
+// threads stores 128 CC contiguous bytes).  T of halo pixels is computed by every workgroup that needs it (1.4 x the products:
+// still 2 us of matrix-core time per launch).
+template <int KS, int CC>
+__global__ __launch_bounds__(256, 2) void thin_head_kernel(const IgemmParams p, int tiles_h, int tiles_w) {
+    constexpr int S = 2, PT = (KS - S) / 2;
+    constexpr int DMIN = -((KS - 1 - PT) / S), DMAX = (S - 1 + PT) / S;
+    constexpr int TH = 8, TW = 16;
+    constexpr int HRr = TH + DMAX - DMIN, HCc = TW + DMAX - DMIN, HPIX = HRr * HCc;
+    constexpr int MB = (HPIX + 31) / 32;
+    constexpr int NCOL = KS * KS * CC, NT = (NCOL + 31) / 32;
+    constexpr int TP = NT * 32 + 1;                        // T pitch (floats): odd, so that consecutive pixels fall on consecutive banks
+    constexpr int XP = 144;                                // bytes per halo pixel record: 32 x bf16 hi | 32 x bf16 lo | 16 pad
+    constexpr int NLOAD = (HPIX * 8 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* xs = lds;
+    float* T = reinterpret_cast<float*>(lds + MB * 32 * XP);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w; b /= tiles_w;
+    const int th = b % tiles_h;
+    const int n = b / tiles_h;
+    const int u0 = th * TH, v0 = tw * TW;
+    // ---- halo: every load in flight before the first LDS write; out-of-image pieces get an offset beyond num_records and the
+    // hardware returns zeros (a select on a plain load becomes a branch around the load in hipcc's hands, with a wait at every join)
+    {
+        float4 v[NLOAD];
+        const int64_t img_bytes = (int64_t)p.Ha * p.Wa * p.a_ld * 4;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A) + (int64_t)n * p.Ha * p.Wa * p.a_ld, 0, (int)img_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int idx = tid + 256 * i;
+            const int pix = idx >> 3, c4 = idx & 7;
+            const int hr = pix / HCc, hc = pix - hr * HCc;
+            const int ih = u0 + DMIN + hr, iw = v0 + DMIN + hc;
+            const bool ok = pix < HPIX && (unsigned)ih < (unsigned)p.Ha && (unsigned)iw < (unsigned)p.Wa;
+            const int off = ok ? ((ih * p.Wa + iw) * p.a_ld + c4 * 4) * 4 : 0x7ffffff0;
+            v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < HPIX * 8) {
+                const float4 t = v[i];
+                const float h0 = (float)(__bf16)t.x, h1 = (float)(__bf16)t.y, h2 = (float)(__bf16)t.z, h3 = (float)(__bf16)t.w;
+                uint2 hi, lo;
+                hi.x = tpack2(t.x, t.y); hi.y = tpack2(t.z, t.w);
+                lo.x = tpack2(t.x - h0, t.y - h1); lo.y = tpack2(t.z - h2, t.w - h3);
+                unsigned char* d = xs + (idx >> 3) * XP + (idx & 7) * 8;
+                *reinterpret_cast<uint2*>(d) = hi;
+                *reinterpret_cast<uint2*>(d + 64) = lo;
+            }
+        }
+    }
+    // ---- filter fragments: column nt * 32 + li = (P * KS + Q) * CC + c, channels 16 s + 8 lh + 0..7 (contiguous: w_ks = 1); all
+    // loads unconditional (clamped column) and in flight together
+    tbf16x8 bh[NT][2], bl[NT][2];
+    {
+        float4 wv[NT][2][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = min(nt * 32 + li, NCOL - 1);
+            const int tap = col / CC, c = col - tap * CC;
+            const float* wsrc = p.Wt + (int64_t)tap * p.w_tap_stride + (int64_t)c * p.w_ns + lh * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                wv[nt][s2][0] = *reinterpret_cast<const float4*>(wsrc + s2 * 16);
+                wv[nt][s2][1] = *reinterpret_cast<const float4*>(wsrc + s2 * 16 + 4);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bool okc = nt * 32 + li < NCOL;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float w[8] = {wv[nt][s2][0].x, wv[nt][s2][0].y, wv[nt][s2][0].z, wv[nt][s2][0].w,
+                                    wv[nt][s2][1].x, wv[nt][s2][1].y, wv[nt][s2][1].z, wv[nt][s2][1].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float wj = okc ? w[j] : 0.f;
+                    const __bf16 h = (__bf16)wj;
+                    bh[nt][s2][j] = h;
+                    bl[nt][s2][j] = (__bf16)(wj - (float)h);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- T = X W^T for this wave's pixel blocks
+    for (int m = wave; m < MB; m += 4) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        const unsigned char* ap = xs + (m * 32 + li) * XP + lh * 16;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const tbf16x8 ah = __builtin_bit_cast(tbf16x8, *reinterpret_cast<const uint4*>(ap + s2 * 32));
+            const tbf16x8 al = __builtin_bit_cast(tbf16x8, *reinterpret_cast<const uint4*>(ap + 64 + s2 * 32));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nt][s2], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nt][s2], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nt][s2], acc[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TP + nt * 32 + li] = acc[nt][r];
+    }
+    __syncthreads();
+    // ---- gather: thread = (row parity a, tile position (tu, tv)): output row 2 u + a, columns 2 v and 2 v + 1, all channels
+    const int tu = (tid >> 4) & 7, tv = tid & 15;
+    const int up = u0 + tu, vp = v0 + tv;
+    if (up >= p.Ha || vp >= p.Wa) return;
+    float bias[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) bias[c] = p.bias ? p.bias[c] : 0.f;
+    const bool is_tanh = p.act == MV3D_ACT_TANH, is_relu = p.act == MV3D_ACT_RELU;
+    const float c1 = p.act == MV3D_ACT_NONE ? 1.f : (p.act == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.leak) : 0.5f);
+    const float c2 = p.act == MV3D_ACT_NONE ? 0.f : (p.act == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.leak) : 0.5f);
+    auto gather = [&](auto pa) {
+        constexpr int a = decltype(pa)::value;
+        float o[2][CC];
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+            for (int c = 0; c < CC; ++c) o[bq][c] = 0.f;
+#pragma unroll
+        for (int dh = DMIN; dh <= DMAX; ++dh) {
+            constexpr int dummy = 0; (void)dummy;
+            const int P = a + PT - S * dh;
+            if (P < 0 || P >= KS) continue;
+#pragma unroll
+            for (int dw = DMIN; dw <= DMAX; ++dw) {
+                const float* trow = T + ((tu + dh - DMIN) * HCc + (tv + dw - DMIN)) * TP;
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) {
+                    const int Q = bq + PT - S * dw;
+                    if (Q < 0 || Q >= KS) continue;
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) o[bq][c] += trow[(P * KS + Q) * CC + c];
+                }
+            }
+        }
+        const int64_t pix0 = (int64_t)(n * p.Hc + up * S + a) * p.Wc + vp * S;
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const float xv = o[bq][c] + bias[c];
+                float y;
+                if (is_tanh) y = tanhf(xv);
+                else {
+                    y = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
+                    y = (is_relu && xv < 0.0f) ? -0.0f : y;
+                }
+                o[bq][c] = y;
+            }
+        float* dst = p.Out + pix0 * p.c_ld;
+        bool stored = false;
+        if constexpr (CC == 2) {
+            if (p.c_ld == 2) { *reinterpret_cast<float4*>(dst) = make_float4(o[0][0], o[0][1], o[1][0], o[1][1]); stored = true; }
+        }
+        if (!stored) {
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+                for (int c = 0; c < CC; ++c) dst[bq * p.c_ld + c] = o[bq][c];
+        }
+    };
+    if (tid < 128) gather(std::integral_constant<int, 0>{}); else gather(std::integral_constant<int, 1>{});
+}
+
+// returns MV3D_OK after dispatching, 1 when the problem is not one of this kernel's (the caller falls back to thin_deconv_s2_tile)
+int try_thin_head(const IgemmParams& p, void* stream, const char* who, double flops, double bytes) {
+    if (disabled_paths() & (4096 | 536870912)) return 1;
+    if (p.gact != MV3D_ACT_NONE) return 1;                      // forward of a head: no gradient mask
+    if ((int64_t)p.Ha * p.Wa * p.a_ld * 4 >= 0x7fffffff) return 1;
+    const int ntaps_all = p.tap_begin[p.so_h * p.so_w];
+    if (p.so_h != 2 || p.so_w != 2 || (ntaps_all != 25 && ntaps_all != 9) || p.Ka != 32 || p.Cc < 1 || p.Cc > 4) return 1;
+    if (p.Hc != 2 * p.Ha || p.Wc != 2 * p.Wa || p.a_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.A) & 15)) return 1;
+    // filter rows contiguous along the 32 feature channels and 16-byte aligned (the reference's [kh, kw, out, in] deconv filters)
+    if (p.w_ks != 1 || p.w_ns % 4 != 0 || p.w_tap_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(p.Wt) & 15)) return 1;
+    const int KS = ntaps_all == 25 ? 5 : 3;
+    const int hpix = KS == 5 ? 10 * 18 : 9 * 17, mb = (hpix + 31) / 32, nt = (KS * KS * p.Cc + 31) / 32;
+    const size_t lds = (size_t)mb * 32 * 144 + (size_t)mb * 32 * (nt * 32 + 1) * 4;
+    if (lds > 160 * 1024) return 1;
+    const int tiles_h = cdiv(p.Ha, 8), tiles_w = cdiv(p.Wa, 16);
+    const int blocks = p.N * tiles_h * tiles_w;
+    using KernelT = void (*)(const IgemmParams, int, int);
+    KernelT kern = nullptr;
+    if (KS == 5) { switch (p.Cc) { case 1: kern = &thin_head_kernel<5, 1>; break; case 2: kern = &thin_head_kernel<5, 2>; break; case 3: kern = &thin_head_kernel<5, 3>; break; default: kern = &thin_head_kernel<5, 4>; break; } }
+    else { switch (p.Cc) { case 1: kern = &thin_head_kernel<3, 1>; break; case 2: kern = &thin_head_kernel<3, 2>; break; case 3: kern = &thin_head_kernel<3, 3>; break; default: kern = &thin_head_kernel<3, 4>; break; } }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();            // recording without a device: the attribute call fails and nothing is launched
+    IgemmParams q = p;
+    q.ksplit = 1;
+    static const char* names[4] = {"thin_head<1>", "thin_head<2>", "thin_head<3>", "thin_head<4>"};
+    return dispatch(stream, OpInfo{names[p.Cc - 1], flops, bytes}, [=](hipStream_t s) {
+        kern<<<blocks, 256, lds, s>>>(q, tiles_h, tiles_w);
+        return launched(who);
+    });
 }
 
 // returns MV3D_OK after dispatching, 1 when the problem is not one of this kernel's (the caller falls back to smallc_b3*)

@@ -347,6 +347,17 @@ def test_stride2_forward_conv_rung_at_batch_64():
         L().set_diagnostics(old)
 
 
+def test_vector_alu_head_rung():
+    """diagnostics 536870912: the 32 -> 1..3-channel stride-2 heads on the tiled vector-ALU kernel (thin_deconv_s2_tile), the rung
+    behind the matrix-core form (thin_head)"""
+    old = L().set_diagnostics(536870912)
+    try:
+        run_conv_case(LC.APPFLOW_B64[15])          # flow_field
+        run_conv_case(LC.BASEPRED_B128[16])        # dec_image1/d0 (3 channels)
+    finally:
+        L().set_diagnostics(old)
+
+
 def test_per_item_thin_input_rung_at_batch_64():
     """diagnostics 33554432 | 67108864: the 3- / 2-channel input layers on the kernels the row-band kernels of thin.hip
     replaced (smallc_b3s / smallc_b3 per-item forward, thin_filtgrad on the vector ALUs) stay fallback rungs and stay correct
