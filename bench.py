@@ -472,7 +472,8 @@ def main():
         if args.dump_kernels and rank == 0:
             for n, k in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
                 rate = ("%7.1f TF/s" % (k['flops'] / k['ms'] / 1e9)) if k['flops'] > 0 else ("%7.0f GB/s" % (k['bytes'] / max(k['ms'], 1e-9) / 1e6))
-                print("%-40s launches=%3d  ms/step=%8.4f  %s" % (n, k['launches'], k['ms'], rate), file=sys.stderr)
+                inr = kern.get(n, {}).get('ms', 0.0) if kern else 0.0      # the same label inside the timed region (shares the GPU with the other streams)
+                print("%-40s launches=%3d  ms/step=%8.4f  %s%s" % (n, k['launches'], k['ms'], rate, ("   in-region %8.4f" % inr) if inr > 0 else ""), file=sys.stderr)
     # whole step against the roofline the reference's arithmetic implies: algorithmic fp32 FLOPs (3 440 MFLOP per trained
     # image) over wall time, vs the fp32 MFMA peak -- independent of which matrix-core type carries them
     out["step_f32_equivalent"] = {"tflops": round(value / world * TRAIN_MFLOP_PER_IMAGE_ALL * 1e6 / 1e12, 2),

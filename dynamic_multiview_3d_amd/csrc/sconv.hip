@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
 // S = 1 (round 3, later): the same kernel without the column split takes the stride-1 layers on 32 x 32 and 16 x 16 maps (e1_0,
 // e2_0, d2_0, d3_0, forward and data gradient) from the pipelined kernel, whose persistent one-workgroup-per-CU pipeline has an
 // 11 k-cycle prologue that layers of one or two stages per CU live in.  NK16 = channels / 16 (2 or 4).
-template <int NTAPS, int S, int NK16, bool KSPLIT, bool HAS_G>
+// MT = pixel groups per wave: 1 = 4 x 16 tile; 2 = 8 x 16 tile (each filter fragment feeds two products: the 64 x 64 layers, stride 1)
+template <int NTAPS, int S, int NK16, bool KSPLIT, bool HAS_G, int MT>
 __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int R = 8;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
     const int tw_i = b % x.tiles_w; b /= x.tiles_w;
     const int th_i = b % x.tiles_h;
     const int n = b / x.tiles_h;
-    const int oh0 = th_i * 4, ow0 = tw_i * 16;
+    const int oh0 = th_i * 4 * MT, ow0 = tw_i * 16;
     const int ytile = KSPLIT ? (int)blockIdx.y : (int)blockIdx.y * 2 + half;
     const int n0 = ytile * 32;
 
@@ -441,20 +442,26 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
 
     const int tr0 = 2 * pg + (li >> 4), tc0 = li & 15;                    // this lane's pixel of the 4 x 16 tile (A operand)
     const int a_base = (S * tr0 * x.HCp + tc0) * x.PS + lh * 32 + kofs * 64;
+    const int a_mt = 4 * S * x.HCp * x.PS;                          // second pixel group: four tile rows further down
     int lane_off;
     {
         const IgemmTap tap = p.taps[lane < NTAPS ? lane : 0];
         const int dc = tap.dw - x.dw_min;
         lane_off = ((tap.dh - x.dh_min) * x.HCp + (S == 2 ? (dc & 1) * x.HCe + (dc >> 1) : dc)) * x.PS;
     }
-    f32x16 acc;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    uint4 ab[2][2];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    uint4 ab[2][MT][2];
     auto read_a = [&](int buf, int i) {
         const unsigned char* ap = lds + a_base + __builtin_amdgcn_readlane(lane_off, i / KG) + (i % KG) * 64;
-        ab[buf][0] = *reinterpret_cast<const uint4*>(ap);
-        ab[buf][1] = *reinterpret_cast<const uint4*>(ap + 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ab[buf][mt][0] = *reinterpret_cast<const uint4*>(ap + mt * a_mt);
+            ab[buf][mt][1] = *reinterpret_cast<const uint4*>(ap + mt * a_mt + 16);
+        }
     };
     const int col = n0 + li;
     const float bias = (p.bias && col < p.Cc) ? p.bias[col] : 0.f;
@@ -464,18 +471,20 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
     const float g1 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f + p.gleak) : 0.5f;
     const float g2 = p.gact == MV3D_ACT_LRELU ? 0.5f * (1.0f - p.gleak) : 0.5f;
     const bool g_relu = p.gact == MV3D_ACT_RELU;
-    auto out_pix = [&](int r) {
+    auto out_pix = [&](int mt, int r) {
         const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int tr = 2 * pg + (q >> 4), tc = q & 15;
+        const int tr = 4 * mt + 2 * pg + (q >> 4), tc = q & 15;
         return (n * p.Hc + oh0 + tr) * p.Wc + ow0 + tc;
     };
     // the accumulator registers this wave finishes: all sixteen, or (KSPLIT) eight -- 0-7 by the pair's first wave, 8-15 by its second
     constexpr int NFIN = KSPLIT ? 8 : 16;
     const int rbase = KSPLIT ? half * 8 : 0;
-    float gm[NFIN];
+    float gm[MT][NFIN];
     if constexpr (HAS_G) {          // requested before the ring's look-ahead loads of the chain: landed long before the epilogue
 #pragma unroll
-        for (int j = 0; j < NFIN; ++j) gm[j] = col < p.Cc ? p.gref[(int64_t)out_pix(rbase + j) * p.g_ld + col] : 0.f;
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < NFIN; ++j) gm[mt][j] = col < p.Cc ? p.gref[(int64_t)out_pix(mt, rbase + j) * p.g_ld + col] : 0.f;
     }
     read_a(0, 0);
     auto step = [&](auto ic) {
@@ -483,50 +492,63 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
         load_b(rhi[(i + R - 1) % R], rlo[(i + R - 1) % R], i + R - 1);
         if constexpr (i + 1 < NSTEP) read_a((i + 1) & 1, i + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const sbf16x8 ah = __builtin_bit_cast(sbf16x8, ab[i & 1][0]), al = __builtin_bit_cast(sbf16x8, ab[i & 1][1]);
         const sbf16x8 bh = __builtin_bit_cast(sbf16x8, rhi[i % R]), bl = __builtin_bit_cast(sbf16x8, rlo[i % R]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const sbf16x8 ah = __builtin_bit_cast(sbf16x8, ab[i & 1][mt][0]), al = __builtin_bit_cast(sbf16x8, ab[i & 1][mt][1]);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt], 0, 0, 0);
+        }
         return true;
     };
     sc_chain(step, std::make_integer_sequence<int, NSTEP>{});
-    float fin[NFIN];
+    float fin[MT][NFIN];
     if constexpr (KSPLIT) {
         // the pair's partial tiles: each wave hands over the eight registers the other one finishes; lower channel half + upper channel half
         __syncthreads();                                            // every wave is past its last halo read
-        float* const xch = reinterpret_cast<float*>(lds);           // [wave][8][64]
-        if (half == 0) {
+        float* const xch = reinterpret_cast<float*>(lds);           // [pixel group][wave][8][64]
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xch[(wave * 8 + j) * 64 + lane] = acc[8 + j];
-        } else {
+        for (int mt = 0; mt < MT; ++mt) {
+            if (half == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xch[(wave * 8 + j) * 64 + lane] = acc[j];
+                for (int j = 0; j < 8; ++j) xch[((mt * 4 + wave) * 8 + j) * 64 + lane] = acc[mt][8 + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xch[((mt * 4 + wave) * 8 + j) * 64 + lane] = acc[mt][j];
+            }
         }
         __syncthreads();
-        if (half == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fin[j] = acc[j] + xch[((wave + 2) * 8 + j) * 64 + lane];
-        } else {
+        for (int mt = 0; mt < MT; ++mt) {
+            if (half == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fin[j] = xch[((wave - 2) * 8 + j) * 64 + lane] + acc[8 + j];
+                for (int j = 0; j < 8; ++j) fin[mt][j] = acc[mt][j] + xch[((mt * 4 + wave + 2) * 8 + j) * 64 + lane];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fin[mt][j] = xch[((mt * 4 + wave - 2) * 8 + j) * 64 + lane] + acc[mt][8 + j];
+            }
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) fin[j] = acc[j];
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) fin[mt][j] = acc[mt][j];
     }
 #pragma unroll
-    for (int j = 0; j < NFIN; ++j) {
-        const float xv = fin[j] + bias;
-        float o = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
-        o = (is_relu && xv < 0.0f) ? -0.0f : o;
-        if constexpr (HAS_G) {
-            const float go = gm[j];
-            const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
-            o *= g1 + g2 * (go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f));
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < NFIN; ++j) {
+            const float xv = fin[mt][j] + bias;
+            float o = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
+            o = (is_relu && xv < 0.0f) ? -0.0f : o;
+            if constexpr (HAS_G) {
+                const float go = gm[mt][j];
+                const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
+                o *= g1 + g2 * (go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f));
+            }
+            if (col < p.Cc) p.Out[(int64_t)out_pix(mt, rbase + j) * p.c_ld + col] = o;
         }
-        if (col < p.Cc) p.Out[(int64_t)out_pix(rbase + j) * p.c_ld + col] = o;
-    }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -637,9 +659,11 @@ int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, co
     if (ntaps != 25 && ntaps != 9) return 1;
     if (p.act == MV3D_ACT_TANH || p.gact == MV3D_ACT_TANH || (p.gact != MV3D_ACT_NONE && !p.gref)) return 1;
     if (S == 1) {
-        // the layers whose 16 x 16 x 32-filter task list is shorter than two per CU (what MV3D_CC_TH8_BELOW sends to cconv's 8 x 16 tiles)
+        // MV3D_TC_S1_BELOW: only stride-1 layers with fewer 16 x 16 x 32-filter tasks (default: all of them -- with 8 x 16 tiles the
+        // 64 x 64 layers run at 260 - 268 TFLOP/s against the pipelined kernel's 270 - 285, and the step is 1.3 % faster without its
+        // persistent 150 KiB workgroups on every CU)
         static int s1_below = -1;
-        if (s1_below < 0) { const char* e = getenv("MV3D_TC_S1_BELOW"); s1_below = e ? atoi(e) : 512; }
+        if (s1_below < 0) { const char* e = getenv("MV3D_TC_S1_BELOW"); s1_below = e ? atoi(e) : (1 << 30); }
         if (p.N * cdiv(Hp, 16) * cdiv(Wp, 16) * cdiv(p.Cc, 32) >= s1_below) return 1;
     }
     int dh_min = 127, dh_max = -127, dw_min = 127, dw_max = -127;
@@ -648,9 +672,13 @@ int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, co
         dw_min = std::min<int>(dw_min, p.taps[t].dw); dw_max = std::max<int>(dw_max, p.taps[t].dw);
     }
     if (ntaps == 25 ? (dh_max - dh_min != 4 || dw_max - dw_min != 4) : (dh_max - dh_min != 2 || dw_max - dw_min != 2)) return 1;
+    // 8 x 16 tiles (two pixel groups per wave) for stride-1 32-channel layers with at least MV3D_TC_MT2_MIN 4 x 16 tiles
+    static int mt2_min = -1;
+    if (mt2_min < 0) { const char* e = getenv("MV3D_TC_MT2_MIN"); mt2_min = e ? atoi(e) : 1000; }
+    const int MTv = (S == 1 && p.Ka == 32 && Hp % 8 == 0 && p.N * (Hp / 4) * (Wp / 16) >= mt2_min) ? 2 : 1;
     SconvParams x = {};
-    x.G = 1; x.TH = 4; x.tiles_h = Hp / 4; x.tiles_w = Wp / 16;
-    x.HRi = 3 * S + (dh_max - dh_min + 1);
+    x.G = 1; x.TH = 4 * MTv; x.tiles_h = Hp / x.TH; x.tiles_w = Wp / 16;
+    x.HRi = (x.TH - 1) * S + (dh_max - dh_min + 1);
     x.HC = 15 * S + (dw_max - dw_min + 1);
     x.PS = p.Ka * 4 + 32;
     x.HCe = (x.HC + 1) / 2;
@@ -662,7 +690,7 @@ int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, co
     x.c8 = p.Ka / 8; x.inv_c8 = inv32(x.c8); x.inv_hc = inv32(x.HC); x.inv_hri = inv32(x.HRi);
     x.units = x.HRi * x.HC * x.c8;
     if (x.units >= 65536) return 1;
-    const size_t lds = std::max((size_t)x.HRi * x.HCp * x.PS, (size_t)8 * 1024);
+    const size_t lds = std::max((size_t)x.HRi * x.HCp * x.PS, (size_t)16 * 1024);
     if (lds > 80 * 1024) return 1;
     int rc = MV3D_OK;
     const uint4* wf = bconv_get_filter(p, ws, ws_bytes, stream, &x.ntiles, &rc);
@@ -678,11 +706,12 @@ int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, co
     const int nk = x.nk16;
     using KernelT = void (*)(const IgemmParams, const SconvParams, const uint4*);
     KernelT kern = nullptr;
-#define MV3D_S2_PICK(T_, S_, N_) kern = ksplit ? (hg ? &s2conv_kernel<T_, S_, N_, true, true> : &s2conv_kernel<T_, S_, N_, true, false>) \
-                                               : (hg ? &s2conv_kernel<T_, S_, N_, false, true> : &s2conv_kernel<T_, S_, N_, false, false>)
-    if (S == 2) { if (k5) MV3D_S2_PICK(25, 2, 2); else MV3D_S2_PICK(9, 2, 2); }
-    else if (nk == 2) { if (k5) MV3D_S2_PICK(25, 1, 2); else MV3D_S2_PICK(9, 1, 2); }
-    else { if (k5) MV3D_S2_PICK(25, 1, 4); else MV3D_S2_PICK(9, 1, 4); }
+#define MV3D_S2_PICK(T_, S_, N_, M_) kern = ksplit ? (hg ? &s2conv_kernel<T_, S_, N_, true, true, M_> : &s2conv_kernel<T_, S_, N_, true, false, M_>) \
+                                                   : (hg ? &s2conv_kernel<T_, S_, N_, false, true, M_> : &s2conv_kernel<T_, S_, N_, false, false, M_>)
+    if (S == 2) { if (k5) MV3D_S2_PICK(25, 2, 2, 1); else MV3D_S2_PICK(9, 2, 2, 1); }
+    else if (nk == 2 && MTv == 2) { if (k5) MV3D_S2_PICK(25, 1, 2, 2); else MV3D_S2_PICK(9, 1, 2, 2); }
+    else if (nk == 2) { if (k5) MV3D_S2_PICK(25, 1, 2, 1); else MV3D_S2_PICK(9, 1, 2, 1); }
+    else { if (k5) MV3D_S2_PICK(25, 1, 4, 1); else MV3D_S2_PICK(9, 1, 4, 1); }
 #undef MV3D_S2_PICK
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipGetLastError();            // recording without a device: the attribute call fails and nothing is launched
@@ -690,7 +719,7 @@ int try_s2conv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, co
         fprintf(stderr, "[mv3d] %-22s s2conv N=%d in %dx%dx%d (stride %d) out %dx%dx%d taps=%d halo %dx%d (pitch %d) lds=%zu grid=%dx%d %s %.2f GFLOP\n",
                 who, p.N, p.Ha, p.Wa, p.Ka, S, p.Hc, p.Wc, p.Cc, ntaps, x.HRi, x.HC, x.HCp, lds, grid.x, grid.y, ksplit ? "ksplit" : "N64", flops * 1e-9);
     const IgemmParams pc = p;
-    const char* name = intern_label("s2conv<%s,s%d,C%d,%s%s>", k5 ? "5x5" : "3x3", S, p.Ka, ksplit ? "N32" : "N64", hg ? ",gmask" : "");
+    const char* name = intern_label("s2conv<%s,s%d,C%d,%s%s%s>", k5 ? "5x5" : "3x3", S, p.Ka, ksplit ? "N32" : "N64", MTv == 2 ? ",128px" : "", hg ? ",gmask" : "");
     return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
         kern<<<grid, 256, lds, s>>>(pc, x, wf);
         return launched(who);

@@ -338,10 +338,10 @@ def test_stride2_transposed_conv_rung_at_batch_64():
 
 def test_stride2_forward_conv_rung_at_batch_64():
     """diagnostics 268435456: the stride-2 convolutions e1 / e2 (and the data gradients of d1 / d2) on the unrolled 64-pixel
-    kernel (bconvu), the rung behind s2conv"""
+    kernel (bconvu) and the stride-1 5 x 5 layers on the pipelined kernel (cconv, both tile sizes), the rungs behind s2conv"""
     old = L().set_diagnostics(268435456)
     try:
-        for i in (2, 4, 12, 14):          # e1, e2, d2, d1
+        for i in (2, 4, 12, 14, 1, 3, 5, 13):          # e1, e2, d2, d1; e0_0 / d1_0, e1_0, e2_0 / d3_0, d2_0
             run_conv_case(LC.APPFLOW_B64[i])
     finally:
         L().set_diagnostics(old)
@@ -381,7 +381,7 @@ def test_model_step_at_benchmark_batch():
     model = AppearanceFlowModel({'batch_size': B, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cuda')
     g = model.graph
     names = {o[0] for plan in (g.plan_fwd, g.plan_bwd) for o in _lib.plan_ops(plan)}
-    assert 'bconv_split_all' in names and any(n.startswith('cconv<5x5,256px') for n in names)
+    assert 'bconv_split_all' in names and any(n.startswith('s2conv<5x5,s1,C32,N32,128px') for n in names)
     variables = _perturb_biases(g)
     feeds = appflow_feeds(np.random.default_rng(3), B)
     builder = omodels.appearance_flow_builder('base')

@@ -68,7 +68,7 @@ def test_appflow_batch64_labels_are_parity_tested():
     from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
     m = AppearanceFlowModel({'batch_size': 64, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cpu')
     labels = _plan_labels(m.graph)
-    assert any(l.startswith('cconv<5x5,256px') for l in labels)            # the kernel that carries the step (e0_0 / d1_0)
+    assert any(l.startswith('s2conv<5x5,s1,C32,N32,128px') for l in labels)      # the kernel that carries the step (e0_0 / d1_0)
     _assert_covered(labels, _case_labels(LC.APPFLOW_B64, LC.FC_B64), 'AppearanceFlowModel B=64')
 
 
@@ -99,7 +99,7 @@ def test_small_batch_cases_do_not_cover_the_benchmark():
     small = [(LC.CONV, 2, 64, 64, 32, 32, 5, 1, 32, 32, True), (LC.CONV, 2, 64, 64, 32, 32, 5, 2, 32, 32, True),
              (LC.DECONV, 2, 64, 64, 32, 64, 5, 2, 32, 64, True)]
     big = _case_labels(LC.APPFLOW_B64, [])
-    assert not {l for l in big if l.startswith('cconv<5x5,256px')} <= _case_labels(small, [])
+    assert not {l for l in big if l.startswith('s2conv<5x5,s1,C32,N32,128px')} <= _case_labels(small, [])
 
 
 def test_extra_cases_reach_the_kernel_instances_they_are_there_for():
