@@ -443,7 +443,7 @@ def main():
         hk = {}
         for label, what in (('resample_loss', 'warp + bilinear sampler + pixel loss + flow gradient (tf_utils.py:35-42,18-19)'),
                             ('smallc_band', 'e0: conv 128x128x3 -> 64x64x32, 5x5 stride 2, forward (appearance_flow_model.py:88)'),
-                            ('thin_deconv_s2<2>', 'flow_field: deconv 64x64x32 -> 128x128x2, 5x5 stride 2, forward (appearance_flow_model.py:125)'),
+                            ('thin_head<2>', 'flow_field: deconv 64x64x32 -> 128x128x2, 5x5 stride 2, forward (appearance_flow_model.py:125)'),
                             ('smallc_band<gmask>', 'flow_field: data gradient'),
                             ('thin_wgrad', 'filter gradients of e0 and flow_field (two launches)'),
                             ('grad_finalize_adam', 'slab sums of all conv filter gradients + their optimiser update'),
