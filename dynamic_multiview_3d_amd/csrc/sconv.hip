@@ -223,7 +223,9 @@ template <int KSZ> struct PhaseTaps;
 template <> struct PhaseTaps<5> { static constexpr int b[5] = {0, 4, 10, 16, 25}; };
 template <> struct PhaseTaps<3> { static constexpr int b[5] = {0, 4, 6, 8, 9}; };
 
-template <int KSZ, int NK16, bool HAS_G>
+// TR = 8: as described.  TR = 4 (layers with fewer than 256 8 x 16 tiles): 4 x 16 tiles, waves 0 / 1 own the two 32-pixel halves
+// for phases 0 and 3 (4 + 9 of the 25 taps), waves 2 / 3 the same pixels for phases 1 and 2 (6 + 6): twice the workgroups, half the chain.
+template <int KSZ, int NK16, bool HAS_G, int TR>
 __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, const SconvParams x, const uint4* __restrict__ Wf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int R = 8;
@@ -236,7 +238,9 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
     const int tw_i = b % x.tiles_w; b /= x.tiles_w;
     const int th_i = b % x.tiles_h;
     const int n = b / x.tiles_h;
-    const int oh0 = th_i * 8, ow0 = tw_i * 16;
+    const int oh0 = th_i * TR, ow0 = tw_i * 16;
+    const int pgw = TR == 8 ? wave : (wave & 1);                      // pixel group (two tile rows) of this wave
+    const int half = TR == 8 ? 0 : (wave >> 1);                        // TR = 4: which pair of phases
     const int n0 = blockIdx.y * 32;
 
     uint4 rhi[R], rlo[R];
@@ -249,8 +253,11 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
         hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, so, 0));
         lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, so, 0));
     };
+    // global step (tap * NK16 + channel group) of local step j of this wave's chain
+    constexpr int B1 = PhaseTaps<KSZ>::b[1] * NK16, B3 = PhaseTaps<KSZ>::b[3] * NK16;
+    auto gstep = [&](int j) { return TR == 8 ? j : (half == 0 ? (j < B1 ? j : j + (B3 - B1)) : j + B1); };
 #pragma unroll
-    for (int u = 0; u < R - 1; ++u) load_b(rhi[u], rlo[u], u);
+    for (int u = 0; u < R - 1; ++u) load_b(rhi[u], rlo[u], gstep(u));
 
     // ---- halo of the tile, all channels: fp32 global -> bf16 hi | lo units in LDS
     {
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
     }
     __syncthreads();
 
-    const int tr0 = 2 * wave + (li >> 4), tc0 = li & 15;                  // this lane's pixel of the 8 x 16 tile (A operand)
+    const int tr0 = 2 * pgw + (li >> 4), tc0 = li & 15;                   // this lane's pixel of the tile (A operand)
     const int a_base = (tr0 * x.HC + tc0) * x.PS + lh * 32;
     int lane_off;
     {
@@ -310,49 +317,64 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
     // output pixel of accumulator register r of phase (phh, phw), minus the lane-independent part
     auto out_pix = [&](int r, int phh, int phw) {
         const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int tr = 2 * wave + (q >> 4), tc = q & 15;
+        const int tr = 2 * pgw + (q >> 4), tc = q & 15;
         return ((n * p.Hc + (oh0 + tr) * 2 + phh) * p.Wc + (ow0 + tc) * 2 + phw);
     };
     float gm[16];
-    read_a(0, 0);
-    auto step = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int tap = i / NK16;
-        constexpr int ph = tap < PhaseTaps<KSZ>::b[1] ? 0 : (tap < PhaseTaps<KSZ>::b[2] ? 1 : (tap < PhaseTaps<KSZ>::b[3] ? 2 : 3));
-        constexpr bool first = i == PhaseTaps<KSZ>::b[ph] * NK16, last = i + 1 == PhaseTaps<KSZ>::b[ph + 1] * NK16;
-        if constexpr (first) {
+    // HALF = -1: all four phases (TR = 8); 0: phases 0 and 3; 1: phases 1 and 2.  J = local step of the chain, I = global step.
+    auto run = [&](auto hsel) {
+        constexpr int HALF = decltype(hsel)::value;
+        constexpr int NLOC = HALF < 0 ? NSTEP : (HALF == 0 ? B1 + (NSTEP - B3) : B3 - B1);
+        constexpr int OFF1 = HALF < 0 ? 0 : (HALF == 0 ? 0 : B1);
+        read_a(0, OFF1);
+        auto step = [&](auto ic) {
+            constexpr int j = decltype(ic)::value;
+            constexpr int i = HALF == 0 ? (j < B1 ? j : j + (B3 - B1)) : j + OFF1;
+            constexpr int inext = HALF == 0 ? (j + 1 < B1 ? j + 1 : j + 1 + (B3 - B1)) : j + 1 + OFF1;
+            constexpr int tap = i / NK16;
+            constexpr int ph = tap < PhaseTaps<KSZ>::b[1] ? 0 : (tap < PhaseTaps<KSZ>::b[2] ? 1 : (tap < PhaseTaps<KSZ>::b[3] ? 2 : 3));
+            constexpr bool first = i == PhaseTaps<KSZ>::b[ph] * NK16, last = i + 1 == PhaseTaps<KSZ>::b[ph + 1] * NK16;
+            if constexpr (first) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            if constexpr (HAS_G) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gm[r] = col < p.Cc ? p.gref[(int64_t)out_pix(r, ph >> 1, ph & 1) * p.g_ld + col] : 0.f;
-            }
-        }
-        load_b(rhi[(i + R - 1) % R], rlo[(i + R - 1) % R], i + R - 1);
-        if constexpr (i + 1 < NSTEP) read_a((i + 1) & 1, i + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const sbf16x8 ah = __builtin_bit_cast(sbf16x8, ab[i & 1][0]), al = __builtin_bit_cast(sbf16x8, ab[i & 1][1]);
-        const sbf16x8 bh = __builtin_bit_cast(sbf16x8, rhi[i % R]), bl = __builtin_bit_cast(sbf16x8, rlo[i % R]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-        if constexpr (last) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float xv = acc[r] + bias;
-                float y = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
-                y = (is_relu && xv < 0.0f) ? -0.0f : y;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 if constexpr (HAS_G) {
-                    const float go = gm[r];
-                    const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
-                    y *= g1 + g2 * (go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gm[r] = col < p.Cc ? p.gref[(int64_t)out_pix(r, ph >> 1, ph & 1) * p.g_ld + col] : 0.f;
                 }
-                if (col < p.Cc) p.Out[(int64_t)out_pix(r, ph >> 1, ph & 1) * p.c_ld + col] = y;
             }
-        }
-        return true;
+            {
+                constexpr int jl = j + R - 1;                          // look-ahead: local step jl (past the end: the last step again)
+                constexpr int jc = jl < NLOC ? jl : NLOC - 1;
+                constexpr int il = HALF == 0 ? (jc < B1 ? jc : jc + (B3 - B1)) : jc + OFF1;
+                load_b(rhi[(j + R - 1) % R], rlo[(j + R - 1) % R], il);
+            }
+            if constexpr (j + 1 < NLOC) read_a((j + 1) & 1, inext);
+            __builtin_amdgcn_sched_barrier(0);
+            const sbf16x8 ah = __builtin_bit_cast(sbf16x8, ab[j & 1][0]), al = __builtin_bit_cast(sbf16x8, ab[j & 1][1]);
+            const sbf16x8 bh = __builtin_bit_cast(sbf16x8, rhi[j % R]), bl = __builtin_bit_cast(sbf16x8, rlo[j % R]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            if constexpr (last) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float xv = acc[r] + bias;
+                    float y = __fadd_rn(__fmul_rn(c1, xv), __fmul_rn(c2, fabsf(xv)));
+                    y = (is_relu && xv < 0.0f) ? -0.0f : y;
+                    if constexpr (HAS_G) {
+                        const float go = gm[r];
+                        const bool neg = g_relu ? (__float_as_uint(go) >> 31) != 0 : go < 0.0f;
+                        y *= g1 + g2 * (go > 0.0f ? 1.0f : (neg ? -1.0f : 0.0f));
+                    }
+                    if (col < p.Cc) p.Out[(int64_t)out_pix(r, ph >> 1, ph & 1) * p.c_ld + col] = y;
+                }
+            }
+            return true;
+        };
+        sc_chain(step, std::make_integer_sequence<int, NLOC>{});
     };
-    sc_chain(step, std::make_integer_sequence<int, NSTEP>{});
+    if constexpr (TR == 8) run(std::integral_constant<int, -1>{});
+    else { if (half == 0) run(std::integral_constant<int, 0>{}); else run(std::integral_constant<int, 1>{}); }
 }
 
 // Stride-2 convolution forward (and the data gradient of a stride-2 transposed convolution) on images of whole 4 x 16 output
@@ -563,6 +585,8 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     if (nph == 4 && (p.so_h != 2 || p.so_w != 2 || p.Hp[1] != Hp || p.Wp[1] != Wp)) return 1;
     const int ipx = Hp * Wp;
     // sconv4_kernel: 4-phase problems on phase grids of whole 8 x 16 tiles (the small-image form below takes grids up to 64 pixels)
+    // (4 x 16 tiles where the layer has fewer than 256 workgroups of 8 x 16)
+    const bool tile4 = nph == 4 && Hp % 8 == 0 && Wp % 16 == 0 && p.N * (Hp / 8) * (Wp / 16) * cdiv(p.Cc, 32) < 256 && !getenv("MV3D_S4_NO_TR4");
     const bool tile = nph == 4 && ipx > 64 && Hp % 8 == 0 && Wp % 16 == 0 && p.sa_h == 1 && p.sa_w == 1 && !(disabled_paths() & 134217728);
     if (!tile && ((ipx & (ipx - 1)) || (Wp & (Wp - 1)) || Wp < 4 || Wp > 32 || ipx < 16 || ipx > 64)) return 1;
     const int ntaps = p.tap_begin[nph];
@@ -575,7 +599,7 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
     }
     SconvParams x = {};
     x.tiles_w = 1;
-    if (tile) { x.G = 1; x.TH = 8; x.tiles_h = Hp / 8; x.tiles_w = Wp / 16; }
+    if (tile) { x.G = 1; x.TH = tile4 ? 4 : 8; x.tiles_h = Hp / x.TH; x.tiles_w = Wp / 16; }
     else if (ipx == 16) { x.G = 2; x.TH = Hp; x.tiles_h = 1; }
     else { x.G = 1; x.TH = 32 / Wp; x.tiles_h = Hp / x.TH; }
     if (x.TH < 1 || x.TH * x.tiles_h != Hp) return 1;
@@ -623,15 +647,18 @@ int try_sconv(const IgemmParams& p, void* ws, size_t ws_bytes, void* stream, con
             const bool k5 = ntaps == 25;
             static bool attr4 = false;
             if (!attr4) {
-#define MV3D_S4_ATTR(K_, N_, G_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv4_kernel<K_, N_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define MV3D_S4_ATTR(K_, N_, G_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv4_kernel<K_, N_, G_, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                                      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv4_kernel<K_, N_, G_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); } while (0)
                 MV3D_S4_ATTR(5, 2, false); MV3D_S4_ATTR(5, 2, true); MV3D_S4_ATTR(5, 4, false); MV3D_S4_ATTR(5, 4, true);
                 MV3D_S4_ATTR(3, 2, false); MV3D_S4_ATTR(3, 2, true); MV3D_S4_ATTR(3, 4, false); MV3D_S4_ATTR(3, 4, true);
 #undef MV3D_S4_ATTR
                 attr4 = true;
             }
-            const char* name = intern_label("sconv4<%s,C%d%s>", k5 ? "5x5" : "3x3", nk * 16, hg ? ",gmask" : "");
+            const bool t4 = x.TH == 4;
+            const char* name = intern_label("sconv4<%s,C%d%s%s>", k5 ? "5x5" : "3x3", nk * 16, t4 ? ",64px" : "", hg ? ",gmask" : "");
             return dispatch(stream, OpInfo{name, flops, bytes}, [=](hipStream_t s) {
-#define MV3D_S4(K_, N_) do { if (hg) sconv4_kernel<K_, N_, true><<<g4, 256, lds, s>>>(pc, x, wf); else sconv4_kernel<K_, N_, false><<<g4, 256, lds, s>>>(pc, x, wf); } while (0)
+#define MV3D_S4(K_, N_) do { if (t4) { if (hg) sconv4_kernel<K_, N_, true, 4><<<g4, 256, lds, s>>>(pc, x, wf); else sconv4_kernel<K_, N_, false, 4><<<g4, 256, lds, s>>>(pc, x, wf); } \
+                             else { if (hg) sconv4_kernel<K_, N_, true, 8><<<g4, 256, lds, s>>>(pc, x, wf); else sconv4_kernel<K_, N_, false, 8><<<g4, 256, lds, s>>>(pc, x, wf); } } while (0)
                 if (k5) { if (nk == 4) MV3D_S4(5, 4); else MV3D_S4(5, 2); }
                 else { if (nk == 4) MV3D_S4(3, 4); else MV3D_S4(3, 2); }
 #undef MV3D_S4
