@@ -330,12 +330,22 @@ class LinearNode(Node):
             g._fused_nodes.append(self)
             self.m.has_grad = self.b.has_grad = True
             return
+        # The angle MLP (a0 -> a1 -> a2, appearance_flow_model.py:101-103): nothing on the main stream reads the input gradient of a
+        # small fc layer whose input comes from another small fc layer, so its data gradient rides the filter-gradient stream too
+        # (two 5 us launches off the dependent chain of the reverse pass)
+        side_dgrad = (x.requires_grad and fin <= 128 and fout <= 128 and x.grad_consumers <= 1 and
+                      any(isinstance(n, LinearNode) and n.y.storage is x.storage and n.y.ch_off == x.ch_off and n.x.C <= 128
+                          for n in g.nodes))
         ws_side = g.begin_side(25.0, 32.0 if x.requires_grad else 0.0)
         g.lib.fc_wgrad(B, fin, fout, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
                        ws_side, g.ws_bytes, g.stream)
+        if side_dgrad:
+            epi = _epi(mask_of=x)
+            g.lib.fc_dgrad(B, fin, fout, y.grad_ptr, y.ld, self.m.ptr, x.grad_ptr, x.ld, C.byref(epi), ws_side, g.ws_bytes, g.stream)
+            _note_grad_written(x, x.act != ACT_NONE)
         g.end_side()
         self.m.has_grad = self.b.has_grad = True
-        if x.requires_grad:
+        if x.requires_grad and not side_dgrad:
             epi = _epi(mask_of=x)
             g.lib.fc_dgrad(B, fin, fout, y.grad_ptr, y.ld, self.m.ptr, x.grad_ptr, x.ld, C.byref(epi),
                            g.ws_ptr, g.ws_bytes, g.stream)
