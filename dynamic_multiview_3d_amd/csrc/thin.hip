@@ -558,7 +558,49 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinWgParams p) {
         const int ih0 = oh0 * 2 - p.pt;
         const int xoff = p.pl * p.C;
         constexpr int UB = 5;
-        for (int base = 0; base < total; base += 256 * UB) {
+        // Branch-free loads through buffer descriptors (rows outside the image and indices past the band get an offset beyond
+        // num_records: zeros): with `ok ? load : 0` hipcc branches around every load and then waits with vmcnt(0) -- for the dY
+        // prefetch below as well, i.e. for the whole 33 MB dY stream of the layer before the first row is converted.
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.img) + (int64_t)n * p.H * p.W * p.C, 0, p.H * p.W * p.C * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feat) + (int64_t)n * p.Ho * p.Wo * p.feat_ld, 0, p.Ho * p.Wo * p.feat_ld * 4, 0x00020000);
+        auto convert = [&](const float4& t, int lof) {
+            const float xs[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const __bf16 h = (__bf16)xs[j];
+                const __bf16 l = (__bf16)(xs[j] - (float)h);
+                l_hi[lof + j] = __builtin_bit_cast(unsigned short, h);
+                l_lo[lof + j] = __builtin_bit_cast(unsigned short, l);
+            }
+        };
+        {
+            float4 v[UB];
+            int lofs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int idx = u * 256 + tid;
+                const int r = (int)__umulhi((unsigned)idx, p.inv_row_f4), f = idx - r * row_f4;
+                const int ih = ih0 + r;
+                const bool ok = idx < total && (unsigned)ih < (unsigned)p.H;
+                v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (ih * p.W * p.C + 4 * f) * 4 : 0x7ffffff0, 0, 0));
+                lofs[u] = idx < total ? r * p.rp + xoff + 4 * f : -1;
+            }
+            // this wave's first output row of dY: requested BEHIND the first round of row loads (vmcnt retires in order: in
+            // front of them, the rows waited for the whole dY stream of the layer -- 12 k cycles per band in the stamps)
+            // and consumed after the planes are built; the remaining rows of a wave are loaded row by row
+            {
+                const int frow = (min(oh0 + wave, p.Ho - 1) * p.Wo * p.feat_ld + k0 + li) * 4;
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        pre[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(fr, (k_ok && u * 16 < p.Wo) ? frow + (u * 16 + 8 * lh + j) * p.feat_ld * 4 : 0x7ffffff0, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (lofs[u] >= 0) convert(v[u], lofs[u]);
+        }
+        for (int base = 256 * UB; base < total; base += 256 * UB) {       // wider images: the rest of the band's rows
             float4 v[UB];
             int lofs[UB];
 #pragma unroll
@@ -567,33 +609,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinWgParams p) {
                 const int r = (int)__umulhi((unsigned)idx, p.inv_row_f4), f = idx - r * row_f4;
                 const int ih = ih0 + r;
                 const bool ok = idx < total && (unsigned)ih < (unsigned)p.H;
-                const float4 t = *reinterpret_cast<const float4*>(p.img + (ok ? ((int64_t)(n * p.H + ih) * p.W * p.C + 4 * f) : 0));
-                v[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (ih * p.W * p.C + 4 * f) * 4 : 0x7ffffff0, 0, 0));
                 lofs[u] = idx < total ? r * p.rp + xoff + 4 * f : -1;
             }
-            if (base == 0) {
-                // this wave's first output row of dY: requested BEHIND the first round of row loads (vmcnt retires in order: in
-                // front of them, the rows waited for the whole 33 MB dY stream of the layer -- 12 k cycles per band in the stamps)
-                // and consumed after the planes are built; the remaining rows of a wave are loaded row by row
-                const float* frow = p.feat + (int64_t)((n * p.Ho + min(oh0 + wave, p.Ho - 1)) * p.Wo) * p.feat_ld + k0 + li;
 #pragma unroll
-                for (int u = 0; u < PF; ++u)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pre[u][j] = (k_ok && u * 16 < p.Wo) ? frow[(int64_t)(u * 16 + 8 * lh + j) * p.feat_ld] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                if (lofs[u] >= 0) {
-                    const float xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const __bf16 h = (__bf16)xs[j];
-                        const __bf16 l = (__bf16)(xs[j] - (float)h);
-                        l_hi[lofs[u] + j] = __builtin_bit_cast(unsigned short, h);
-                        l_lo[lofs[u] + j] = __builtin_bit_cast(unsigned short, l);
-                    }
-                }
-            }
+            for (int u = 0; u < UB; ++u)
+                if (lofs[u] >= 0) convert(v[u], lofs[u]);
         }
         const int per_row = p.rp - p.W * p.C;                              // left + right pad elements (host: <= 32)
         const int j = tid & 31;
