@@ -70,58 +70,82 @@ __global__ __launch_bounds__(256) void smallc_band_kernel(const BandParams p) {
     unsigned char* const hi_pl = lds;
     unsigned char* const lo_pl = lds + plane_bytes;
 
-    // ---- filter rows -> fragments (split once per workgroup, through LDS; first, so that its loads overlap the rows')
-    for (int pr = wave; pr < KH; pr += 4) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = 8 * lh + j;
-            v[j] = (e < Cf && k0 + li < p.K) ? p.Wt[((int64_t)pr * Cf + e) * p.K + k0 + li] : 0.f;
-        }
-        tbf16x8 h, l;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
-        fsh[pr][0][lane] = __builtin_bit_cast(uint4, h);
-        fsh[pr][1][lane] = __builtin_bit_cast(uint4, l);
-    }
-    // ---- the band's input rows: fp32 global -> bf16 hi | lo planes (all loads of the workgroup in flight together)
+    // ---- the band's input rows: fp32 global -> bf16 hi | lo planes, and the filter rows -> fragments (split once per workgroup,
+    // through LDS).  All loads of the workgroup are issued before the first conversion, rows first: branch-free through a
+    // buffer descriptor (rows outside the image / indices past the band read zeros), so that hipcc's vmcnt counts stay exact and the
+    // row conversion does not wait for the filter loads behind it.  (The filter used to be loaded AND converted first: two memory
+    // round trips in a row, 15 k cycles before the first product.)
     {
         const int row_f4 = (p.W * p.C) >> 2;                               // float4 pieces per input row
         const int total = p.nrows * row_f4;
         const int ih0 = oh0 * p.sh - p.pt;
         constexpr int UB = 8;
-        for (int base = 0; base < total; base += 256 * UB) {
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X) + (int64_t)n * p.H * p.W * p.C, 0, p.H * p.W * p.C * 4, 0x00020000);
+        auto convert = [&](const float4& t, int lof) {
+            const float h0 = (float)(__bf16)t.x, h1 = (float)(__bf16)t.y, h2 = (float)(__bf16)t.z, h3 = (float)(__bf16)t.w;
+            const unsigned a = tpack2(t.x, t.y), b = tpack2(t.z, t.w);
+            const unsigned c = tpack2(t.x - h0, t.y - h1), d = tpack2(t.z - h2, t.w - h3);
+            if (p.xoff & 1) {          // rows start on an odd plane element (pad * C odd): 2-byte aligned pieces
+                unsigned short* hp = reinterpret_cast<unsigned short*>(hi_pl + lof);
+                unsigned short* lp = reinterpret_cast<unsigned short*>(lo_pl + lof);
+                hp[0] = (unsigned short)a; hp[1] = (unsigned short)(a >> 16); hp[2] = (unsigned short)b; hp[3] = (unsigned short)(b >> 16);
+                lp[0] = (unsigned short)c; lp[1] = (unsigned short)(c >> 16); lp[2] = (unsigned short)d; lp[3] = (unsigned short)(d >> 16);
+            } else {
+                *reinterpret_cast<unsigned*>(hi_pl + lof) = a;
+                *reinterpret_cast<unsigned*>(hi_pl + lof + 4) = b;
+                *reinterpret_cast<unsigned*>(lo_pl + lof) = c;
+                *reinterpret_cast<unsigned*>(lo_pl + lof + 4) = d;
+            }
+        };
+        auto row_piece = [&](int idx, float4& v, int& lof) {
+            const int r = (int)__umulhi((unsigned)idx, p.inv_row_f4), f = idx - r * row_f4;
+            const int ih = ih0 + r;
+            const bool ok = idx < total && (unsigned)ih < (unsigned)p.H;
+            v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (ih * p.W * p.C + 4 * f) * 4 : 0x7ffffff0, 0, 0));
+            lof = idx < total ? (r * p.rp + p.xoff + 4 * f) * 2 : -1;
+        };
+        {
             float4 v[UB];
             int lofs[UB];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int idx = base + u * 256 + tid;
-                const int r = (int)__umulhi((unsigned)idx, p.inv_row_f4), f = idx - r * row_f4;
-                const int ih = ih0 + r;
-                const bool ok = idx < total && (unsigned)ih < (unsigned)p.H;
-                const float4 t = *reinterpret_cast<const float4*>(p.X + (ok ? ((int64_t)(n * p.H + ih) * p.W * p.C + 4 * f) : 0));
-                v[u] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-                lofs[u] = idx < total ? (r * p.rp + p.xoff + 4 * f) * 2 : -1;
-            }
+            for (int u = 0; u < UB; ++u) row_piece(u * 256 + tid, v[u], lofs[u]);
+            // filter rows of this wave (wave 0: rows 0 and 4 of a 5-row filter): unconditional loads from clamped addresses
+            float fv[2][8];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                if (lofs[u] >= 0) {
-                    const float h0 = (float)(__bf16)v[u].x, h1 = (float)(__bf16)v[u].y, h2 = (float)(__bf16)v[u].z, h3 = (float)(__bf16)v[u].w;
-                    const unsigned a = tpack2(v[u].x, v[u].y), b = tpack2(v[u].z, v[u].w);
-                    const unsigned c = tpack2(v[u].x - h0, v[u].y - h1), d = tpack2(v[u].z - h2, v[u].w - h3);
-                    if (p.xoff & 1) {          // rows start on an odd plane element (pad * C odd): 2-byte aligned pieces
-                        unsigned short* hp = reinterpret_cast<unsigned short*>(hi_pl + lofs[u]);
-                        unsigned short* lp = reinterpret_cast<unsigned short*>(lo_pl + lofs[u]);
-                        hp[0] = (unsigned short)a; hp[1] = (unsigned short)(a >> 16); hp[2] = (unsigned short)b; hp[3] = (unsigned short)(b >> 16);
-                        lp[0] = (unsigned short)c; lp[1] = (unsigned short)(c >> 16); lp[2] = (unsigned short)d; lp[3] = (unsigned short)(d >> 16);
-                    } else {
-                        *reinterpret_cast<unsigned*>(hi_pl + lofs[u]) = a;
-                        *reinterpret_cast<unsigned*>(hi_pl + lofs[u] + 4) = b;
-                        *reinterpret_cast<unsigned*>(lo_pl + lofs[u]) = c;
-                        *reinterpret_cast<unsigned*>(lo_pl + lofs[u] + 4) = d;
-                    }
+            for (int it = 0; it < 2; ++it) {
+                const int pr = min(wave + 4 * it, KH - 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = min(8 * lh + j, Cf - 1), kk = min(k0 + li, p.K - 1);
+                    fv[it][j] = p.Wt[((int64_t)pr * Cf + e) * p.K + kk];
                 }
             }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (lofs[u] >= 0) convert(v[u], lofs[u]);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int pr = wave + 4 * it;
+                if (pr < KH) {
+                    tbf16x8 h, l;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float w = (8 * lh + j < Cf && k0 + li < p.K) ? fv[it][j] : 0.f;
+                        h[j] = (__bf16)w; l[j] = (__bf16)(w - (float)h[j]);
+                    }
+                    fsh[pr][0][lane] = __builtin_bit_cast(uint4, h);
+                    fsh[pr][1][lane] = __builtin_bit_cast(uint4, l);
+                }
+            }
+        }
+        for (int base = 256 * UB; base < total; base += 256 * UB) {       // wider images: the rest of the band's rows
+            float4 v[UB];
+            int lofs[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) row_piece(base + u * 256 + tid, v[u], lofs[u]);
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (lofs[u] >= 0) convert(v[u], lofs[u]);
         }
         tstamp(st, wave, lane, sk);                                        // 1: rows split into the planes
         // zero pads left and right of every row (columns outside the image), element by element (they need not be dword aligned)
