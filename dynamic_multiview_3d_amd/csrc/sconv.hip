@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
     {
         const int ih0 = oh0 * p.sa_h + x.dh_min, iw0 = x.dw_min;
         constexpr int UB = 6;                                       // units (2 x 16 bytes) per thread and round
-        for (int base = 0; base < x.units; base += 256 * UB) {
+        // first round straight-line (most halos fit it): the loads go out without the wait for the filter ring that hipcc puts
+        // in front of a loop header; further rounds for larger halos
+        auto stage_round = [&](int base) {
             float4 v[UB][2];
             int lofs[UB];
 #pragma unroll
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(256, 2) void sconv_kernel(const IgemmParams p, cons
                     *reinterpret_cast<uint4*>(lds + lofs[u] + 16) = lo;
                 }
             }
-        }
+        };
+        stage_round(0);
+        for (int base = 256 * UB; base < x.units; base += 256 * UB) stage_round(base);
     }
     __syncthreads();
 
@@ -263,7 +267,9 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
     {
         const int ih0 = oh0 + x.dh_min, iw0 = ow0 + x.dw_min;
         constexpr int UB = 6;
-        for (int base = 0; base < x.units; base += 256 * UB) {
+        // first round straight-line (most halos fit it): the loads go out without the wait for the filter ring that hipcc puts
+        // in front of a loop header; further rounds for larger halos
+        auto stage_round = [&](int base) {
             float4 v[UB][2];
             int lofs[UB];
 #pragma unroll
@@ -288,7 +294,9 @@ __global__ __launch_bounds__(256, 2) void sconv4_kernel(const IgemmParams p, con
                     *reinterpret_cast<uint4*>(lds + lofs[u] + 16) = lo;
                 }
             }
-        }
+        };
+        stage_round(0);
+        for (int base = 256 * UB; base < x.units; base += 256 * UB) stage_round(base);
     }
     __syncthreads();
 
@@ -432,7 +440,9 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
     {
         const int ih0 = oh0 * S + x.dh_min, iw0 = ow0 * S + x.dw_min;
         constexpr int UB = 7;
-        for (int base = 0; base < x.units; base += 256 * UB) {
+        // first round straight-line (most halos fit it): the loads go out without the wait for the filter ring that hipcc puts
+        // in front of a loop header; further rounds for larger halos
+        auto stage_round = [&](int base) {
             float4 v[UB][2];
             int lofs[UB];
 #pragma unroll
@@ -458,7 +468,9 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(const IgemmParams p, con
                     *reinterpret_cast<uint4*>(lds + lofs[u] + 16) = lo;
                 }
             }
-        }
+        };
+        stage_round(0);
+        for (int base = 256 * UB; base < x.units; base += 256 * UB) stage_round(base);
     }
     __syncthreads();
 

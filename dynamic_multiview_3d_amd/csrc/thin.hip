@@ -280,6 +280,8 @@ __global__ __launch_bounds__(256, 2) void thin_head_kernel(const IgemmParams p, 
     const int th = b % tiles_h;
     const int n = b / tiles_h;
     const int u0 = th * TH, v0 = tw * TW;
+    tbf16x8 bh[NT][2], bl[NT][2];
+    float4 wv[NT][2][2];
     // ---- halo: every load in flight before the first LDS write; out-of-image pieces get an offset beyond num_records and the
     // hardware returns zeros (a select on a plain load becomes a branch around the load in hipcc's hands, with a wait at every join)
     {
@@ -296,6 +298,19 @@ __global__ __launch_bounds__(256, 2) void thin_head_kernel(const IgemmParams p, 
             const int off = ok ? ((ih * p.Wa + iw) * p.a_ld + c4 * 4) * 4 : 0x7ffffff0;
             v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
         }
+        // ---- filter fragments: column nt * 32 + li = (P * KS + Q) * CC + c, channels 16 s + 8 lh + 0..7 (contiguous: w_ks = 1); the
+        // loads are unconditional (clamped column) and go out BEHIND the halo's and before its conversion: one round trip for both
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = min(nt * 32 + li, NCOL - 1);
+            const int tap = col / CC, c = col - tap * CC;
+            const float* wsrc = p.Wt + (int64_t)tap * p.w_tap_stride + (int64_t)c * p.w_ns + lh * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                wv[nt][s2][0] = *reinterpret_cast<const float4*>(wsrc + s2 * 16);
+                wv[nt][s2][1] = *reinterpret_cast<const float4*>(wsrc + s2 * 16 + 4);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int idx = tid + 256 * i;
@@ -311,22 +326,7 @@ __global__ __launch_bounds__(256, 2) void thin_head_kernel(const IgemmParams p, 
             }
         }
     }
-    // ---- filter fragments: column nt * 32 + li = (P * KS + Q) * CC + c, channels 16 s + 8 lh + 0..7 (contiguous: w_ks = 1); all
-    // loads unconditional (clamped column) and in flight together
-    tbf16x8 bh[NT][2], bl[NT][2];
     {
-        float4 wv[NT][2][2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = min(nt * 32 + li, NCOL - 1);
-            const int tap = col / CC, c = col - tap * CC;
-            const float* wsrc = p.Wt + (int64_t)tap * p.w_tap_stride + (int64_t)c * p.w_ns + lh * 8;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                wv[nt][s2][0] = *reinterpret_cast<const float4*>(wsrc + s2 * 16);
-                wv[nt][s2][1] = *reinterpret_cast<const float4*>(wsrc + s2 * 16 + 4);
-            }
-        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bool okc = nt * 32 + li < NCOL;
