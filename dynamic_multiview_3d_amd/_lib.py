@@ -26,6 +26,18 @@ class Epilogue(C.Structure):
                 ("gmask_leak", C.c_float), ("gmask_ref", C.c_void_p), ("gmask_ld", C.c_int32)]
 
 
+class FcChainLayer(C.Structure):
+    """mv3d_fc_chain_layer"""
+    _fields_ = [("M", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("y_ld", C.c_int32), ("out", C.c_int32),
+                ("act", C.c_int32), ("leak", C.c_float)]
+
+
+class FcChain(C.Structure):
+    """mv3d_fc_chain"""
+    _fields_ = [("B", C.c_int32), ("nlayers", C.c_int32), ("in_", C.c_int32), ("x_ld", C.c_int32), ("x", C.c_void_p),
+                ("l", FcChainLayer * 4)]
+
+
 class Mv3dError(RuntimeError):
     pass
 
@@ -44,6 +56,8 @@ STATUS_FUNCS = {
     "mv3d_fc_fwd": [_i, _i, _i, _vp, _i, _vp, _vp, _i, _E, _vp, _sz, _vp],
     "mv3d_fc_dgrad": [_i, _i, _i, _vp, _i, _vp, _vp, _i, _E, _vp, _sz, _vp],
     "mv3d_fc_wgrad": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp],
+    "mv3d_fc_wgrad_dgrad": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _E, _vp, _sz, _vp],
+    "mv3d_fc_chain_fwd": [C.POINTER(FcChain), _vp],
     "mv3d_act_fwd": [_i64, _i, _vp, _i, _vp, _i, _i, _f, _vp],
     "mv3d_act_bwd": [_i64, _i, _vp, _i, _vp, _i, _vp, _i, _i, _f, _vp],
     "mv3d_copy2d": [_i64, _i, _vp, _i64, _i64, _vp, _i64, _i, _vp],

@@ -1093,6 +1093,90 @@ __global__ __launch_bounds__(256) void small_fc_wgrad_kernel(int B, int in, int 
         db[o] = acc;
     }
 }
+// wgrad and dgrad of one small layer in one launch: blocks [0, wblocks) are small_fc_wgrad_kernel's, the rest small_fc_dgrad_kernel's
+__global__ __launch_bounds__(256) void small_fc_bwd_kernel(int B, int in, int out, const float* x, int x_ld, const float* dy, int dy_ld,
+                                                          const float* M, float* dM, float* db, float* dx, int dx_ld, const IgemmParams ep,
+                                                          int wblocks) {
+    if ((int)blockIdx.x < wblocks) {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx >= (in + 1) * out) return;
+        const int i = idx / out, o = idx - i * out;
+        float acc = 0.f;
+        if (i < in) {
+#pragma unroll 8
+            for (int b = 0; b < B; ++b) acc = fmaf(x[(int64_t)b * x_ld + i], dy[(int64_t)b * dy_ld + o], acc);
+            dM[(int64_t)i * out + o] = acc;
+        } else if (db) {
+#pragma unroll 8
+            for (int b = 0; b < B; ++b) acc += dy[(int64_t)b * dy_ld + o];
+            db[o] = acc;
+        }
+        return;
+    }
+    const int idx = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (idx >= B * in) return;
+    const int b = idx / in, i = idx - b * in;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < out; ++o) acc = fmaf(dy[(int64_t)b * dy_ld + o], M[(int64_t)i * out + o], acc);
+    dx[(int64_t)b * dx_ld + i] = epilogue_value(ep, acc, b, i);
+}
+
+// A chain of small layers, four batch rows per workgroup: the arithmetic of small_fc_fwd_kernel layer by layer (same products, same
+// order), the activations of a row pass from layer to layer through LDS
+struct FcChainDev {
+    int B, nlayers, in, x_ld;
+    const float* x;
+    struct L { const float* M; const float* bias; float* y; int y_ld, out, act; float leak; } l[MV3D_FC_CHAIN_MAX];
+};
+__global__ __launch_bounds__(256) void fc_chain_fwd_kernel(const FcChainDev c) {
+    extern __shared__ __attribute__((aligned(16))) float cw[];          // all layers' matrices, then the two activation buffers
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * 4;
+    // every load of the workgroup goes out before the first product: the matrices (<= 16 KiB each) and the four input rows -- in the
+    // per-layer kernels a thread's 64 products wait for eight rounds of L2 latency each, which is what a layer's launch costs
+    int woff[MV3D_FC_CHAIN_MAX + 1];
+    {
+        int in = c.in, off = 0;
+        for (int l = 0; l < c.nlayers; ++l) { woff[l] = off; off += in * c.l[l].out; in = c.l[l].out; }
+        woff[c.nlayers] = off;
+    }
+    float* a = cw + ((woff[c.nlayers] + 3) & ~3);                       // [2][4 * 64]
+    {
+        int in = c.in;
+        for (int l = 0; l < c.nlayers; ++l) {
+            const int n = in * c.l[l].out;
+            for (int idx = tid; idx < n; idx += 256) cw[woff[l] + idx] = c.l[l].M[idx];
+            in = c.l[l].out;
+        }
+    }
+    for (int idx = tid; idx < 4 * c.in; idx += 256) {
+        const int r = idx / c.in, i = idx - r * c.in;
+        a[r * 64 + i] = b0 + r < c.B ? c.x[(int64_t)(b0 + r) * c.x_ld + i] : 0.f;
+    }
+    __syncthreads();
+    int in = c.in, cur = 0;
+    for (int l = 0; l < c.nlayers; ++l) {
+        const int out = c.l[l].out;
+        const float* M = cw + woff[l];
+        const float* ain = a + cur * 256;
+        float* aout = a + (cur ^ 1) * 256;
+        for (int idx = tid; idx < 4 * out; idx += 256) {
+            const int r = idx / out, o = idx - r * out;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < in; ++i) acc = fmaf(ain[r * 64 + i], M[i * out + o], acc);
+            if (c.l[l].bias) acc += c.l[l].bias[o];
+            const float v = act_apply(acc, c.l[l].act, c.l[l].leak);
+            if (b0 + r < c.B) c.l[l].y[(int64_t)(b0 + r) * c.l[l].y_ld + o] = v;
+            aout[r * 64 + o] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+        in = out;
+    }
+}
+
 static inline bool is_small_fc(int B, int in, int out) { return !(disabled_paths() & 4) && in <= 256 && out <= 256 && (int64_t)B * (in + out) <= (1 << 16); }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1709,6 +1793,50 @@ int mv3d_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* d
         if (rc != 1) return rc;
     }
     return filtgrad(&g, x, dy, dM, db, ws, wsb, stream, "mv3d_fc_wgrad");
+}
+int mv3d_fc_wgrad_dgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, const void* M,
+                        void* dM, void* db, void* dx, int dx_ld, const mv3d_epilogue* dx_epi, void* ws, size_t wsb, void* stream) {
+    if (B > 0 && in > 0 && out > 0 && x && dy && M && dM && dx && is_small_fc(B, in, out)) {
+        int rc = check_epilogue(dx_epi, "mv3d_fc_wgrad_dgrad");
+        if (rc != MV3D_OK) return rc;
+        IgemmParams ep = {}; fill_epilogue(ep, dx_epi);
+        const int wblocks = cdiv((in + 1) * out, 256), dblocks = cdiv(B * in, 256);
+        return dispatch(stream, OpInfo{"small_fc_bwd", 4.0 * B * in * out, 4.0 * (2.0 * B * in + 2.0 * in * out + 2.0 * B * out)}, [=](hipStream_t s) {
+            small_fc_bwd_kernel<<<wblocks + dblocks, 256, 0, s>>>(B, in, out, (const float*)x, x_ld, (const float*)dy, dy_ld, (const float*)M,
+                                                                  (float*)dM, (float*)db, (float*)dx, dx_ld, ep, wblocks);
+            return launched("small_fc_bwd_kernel");
+        });
+    }
+    int rc = mv3d_fc_wgrad(B, in, out, x, x_ld, dy, dy_ld, dM, db, ws, wsb, stream);
+    if (rc != MV3D_OK) return rc;
+    return mv3d_fc_dgrad(B, in, out, dy, dy_ld, M, dx, dx_ld, dx_epi, ws, wsb, stream);
+}
+int mv3d_fc_chain_fwd(const mv3d_fc_chain* c, void* stream) {
+    if (!c || c->nlayers < 2 || c->nlayers > MV3D_FC_CHAIN_MAX || c->B <= 0 || c->in <= 0 || c->in > 64 || !c->x || c->x_ld < c->in)
+        return fail(MV3D_E_INVAL, "mv3d_fc_chain_fwd: bad chain (2..%d layers, widths <= 64)", MV3D_FC_CHAIN_MAX);
+    if (disabled_paths() & 4) return fail(MV3D_E_UNSUPPORTED, "mv3d_fc_chain_fwd: small fc kernels are disabled (MV3D_DISABLE bit 4)");
+    FcChainDev d = {};
+    d.B = c->B; d.nlayers = c->nlayers; d.in = c->in; d.x_ld = c->x_ld; d.x = (const float*)c->x;
+    double flops = 0.0, bytes = 4.0 * c->B * c->in;
+    int in = c->in;
+    for (int l = 0; l < c->nlayers; ++l) {
+        const mv3d_fc_chain_layer& s = c->l[l];
+        if (!s.M || !s.y || s.out <= 0 || s.out > 64 || s.y_ld < s.out || s.act < 0 || s.act > MV3D_ACT_TANH)
+            return fail(MV3D_E_INVAL, "mv3d_fc_chain_fwd: bad layer %d", l);
+        d.l[l].M = (const float*)s.M; d.l[l].bias = (const float*)s.bias; d.l[l].y = (float*)s.y;
+        d.l[l].y_ld = s.y_ld; d.l[l].out = s.out; d.l[l].act = s.act; d.l[l].leak = s.leak;
+        flops += 2.0 * c->B * in * s.out; bytes += 4.0 * ((double)in * s.out + (double)c->B * s.out);
+        in = s.out;
+    }
+    const int blocks = cdiv(c->B, 4);
+    size_t welems = 0;
+    { int k = c->in; for (int l = 0; l < c->nlayers; ++l) { welems += (size_t)k * c->l[l].out; k = c->l[l].out; } }
+    const size_t lds = (((welems + 3) & ~(size_t)3) + 2 * 256) * sizeof(float);       // <= 66 KiB
+    return dispatch(stream, OpInfo{"small_fc_chain_fwd", flops, bytes}, [=](hipStream_t s) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_chain_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        fc_chain_fwd_kernel<<<blocks, 256, lds, s>>>(d);
+        return launched("fc_chain_fwd_kernel");
+    });
 }
 int mv3d_fc_wgrad_adam(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, void* M, void* adam_m, void* adam_v,
                        void* db, const void* adam_state, void* stream) {

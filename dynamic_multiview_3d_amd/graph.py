@@ -299,8 +299,23 @@ class LinearNode(Node):
     def workspace_bytes(self, g):
         return g.lib.fc_workspace_bytes(self.x.shape[0], self.x.C, self.y.C)
 
+    chain = None        # Graph._find_fc_chains: the list of small layers this one is part of (one launch for all of them)
+
     def forward(self, g):
         x, y = self.x, self.y
+        if self.chain is not None:
+            # a chain of small layers (the angle MLP a0 -> a1 -> a2): ONE launch, recorded at the position of the LAST layer (the
+            # first launch that touches its output: the fc hazard of the pipelined optimiser looks at that position)
+            if self is not self.chain[-1]:
+                return
+            c = _lib.FcChain()
+            first = self.chain[0]
+            c.B, c.nlayers, c.in_, c.x_ld, c.x = first.x.shape[0], len(self.chain), first.x.C, first.x.ld, first.x.ptr
+            for k, n in enumerate(self.chain):
+                c.l[k].M, c.l[k].bias, c.l[k].y, c.l[k].y_ld, c.l[k].out = n.m.ptr, n.b.ptr, n.y.ptr, n.y.ld, n.y.C
+                c.l[k].act, c.l[k].leak = n.act, n.leak
+            g.lib.fc_chain_fwd(C.byref(c), g.stream)
+            return
         epi = _epi(self.b.ptr, self.act, self.leak)
         g.lib.fc_fwd(x.shape[0], x.C, y.C, x.ptr, x.ld, self.m.ptr, y.ptr, y.ld, C.byref(epi), g.ws_ptr, g.ws_bytes, g.stream)
 
@@ -337,12 +352,14 @@ class LinearNode(Node):
                       any(isinstance(n, LinearNode) and n.y.storage is x.storage and n.y.ch_off == x.ch_off and n.x.C <= 128
                           for n in g.nodes))
         ws_side = g.begin_side(25.0, 32.0 if x.requires_grad else 0.0)
-        g.lib.fc_wgrad(B, fin, fout, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
-                       ws_side, g.ws_bytes, g.stream)
         if side_dgrad:
-            epi = _epi(mask_of=x)
-            g.lib.fc_dgrad(B, fin, fout, y.grad_ptr, y.ld, self.m.ptr, x.grad_ptr, x.ld, C.byref(epi), ws_side, g.ws_bytes, g.stream)
+            epi = _epi(mask_of=x)       # both gradients read dy: one launch (mv3d_fc_wgrad_dgrad)
+            g.lib.fc_wgrad_dgrad(B, fin, fout, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.ptr, self.m.grad_ptr, self.b.grad_ptr,
+                                 x.grad_ptr, x.ld, C.byref(epi), ws_side, g.ws_bytes, g.stream)
             _note_grad_written(x, x.act != ACT_NONE)
+        else:
+            g.lib.fc_wgrad(B, fin, fout, x.ptr, x.ld, y.grad_ptr, y.ld, self.m.grad_ptr, self.b.grad_ptr,
+                           ws_side, g.ws_bytes, g.stream)
         g.end_side()
         self.m.has_grad = self.b.has_grad = True
         if x.requires_grad and not side_dgrad:
@@ -676,6 +693,43 @@ class Graph:
             n.fused_loss = (w, t)
             self.fused_terms.add(id(t))
 
+    def _find_fc_chains(self):
+        """Chains of small linear layers (every width <= 64) whose intermediate outputs nobody else reads: one forward launch each
+        (mv3d_fc_chain_fwd).  MV3D_FC_CHAINS=0 keeps one launch per layer."""
+        for n in self.nodes:
+            if isinstance(n, LinearNode):
+                n.chain = None
+        if os.environ.get('MV3D_FC_CHAINS', '1') == '0' or (os.environ.get('MV3D_DISABLE') and int(os.environ['MV3D_DISABLE']) & 4):
+            return
+        def tensors_of(node):
+            for val in vars(node).values():
+                for t in (val if isinstance(val, (list, tuple)) else (val,)):
+                    if isinstance(t, Tensor):
+                        yield t
+        users = {}          # root storage -> nodes that touch it
+        for n in self.nodes:
+            for t in tensors_of(n):
+                users.setdefault(id(t._root()[0]), set()).add(id(n))
+        small = lambda n: isinstance(n, LinearNode) and n.x.C <= 64 and n.y.C <= 64 and n.b is not None
+        nxt = {}
+        for n in self.nodes:
+            if not small(n):
+                continue
+            root = id(n.y._root()[0])
+            if len(users.get(root, ())) != 2:
+                continue
+            for m in self.nodes:
+                if m is not n and small(m) and id(m.x._root()[0]) == root and m.x.ptr == n.y.ptr and m.x.C == n.y.C and m.x.ld == n.y.ld:
+                    nxt[id(n)] = m
+        heads = [n for n in self.nodes if id(n) in nxt and not any(v is n for v in nxt.values())]
+        for h in heads:
+            chain = [h]
+            while id(chain[-1]) in nxt and len(chain) < 4:
+                chain.append(nxt[id(chain[-1])])
+            if len(chain) >= 2:
+                for n in chain:
+                    n.chain = chain
+
     def _emit_losses(self, with_grad):
         if self.loss_expr is None:
             return
@@ -701,6 +755,7 @@ class Graph:
             t.grad_written = t.grad_masked = False
         self._bind_prepared_filters()
         self._fuse_resample_losses()
+        self._find_fc_chains()
         self.plan_fwd = lib.plan_create()
         lib.plan_begin(self.plan_fwd)
         try:

@@ -143,6 +143,30 @@ int mv3d_fc_dgrad(int B, int in, int out, const void* dy, int dy_ld, const void*
                   const mv3d_epilogue* epi, void* workspace, size_t workspace_bytes, void* stream);
 int mv3d_fc_wgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld,
                   void* dM, void* db, void* workspace, size_t workspace_bytes, void* stream);
+/* Filter gradient AND data gradient of one small linear layer in ONE launch (both read dy; the angle MLP's a1 / a2,
+ * appearance_flow_model.py:101-103): the results are those of mv3d_fc_wgrad followed by mv3d_fc_dgrad, bit for bit.  Layers
+ * that are not "small" (the streaming fc kernels take them) are run as those two calls. */
+int mv3d_fc_wgrad_dgrad(int B, int in, int out, const void* x, int x_ld, const void* dy, int dy_ld, const void* M,
+                        void* dM, void* db, void* dx, int dx_ld, const mv3d_epilogue* dx_epi,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* A chain of 2..4 small linear layers (every width <= 64), y_l = act_l(y_{l-1} M_l + b_l), in ONE launch: a workgroup carries
+ * four batch rows through all layers (activations stay in LDS, every y_l is also stored: the reverse pass needs it).  The
+ * results are those of nlayers mv3d_fc_fwd calls, bit for bit. */
+#define MV3D_FC_CHAIN_MAX 4
+typedef struct mv3d_fc_chain_layer {
+    const void* M;        /* [in, out], in = the previous layer's out (first layer: mv3d_fc_chain.in) */
+    const void* bias;     /* [out] or NULL */
+    void* y;              /* [B, out], row stride y_ld */
+    int32_t y_ld, out;
+    int32_t act;          /* MV3D_ACT_* */
+    float leak;
+} mv3d_fc_chain_layer;
+typedef struct mv3d_fc_chain {
+    int32_t B, nlayers, in, x_ld;
+    const void* x;        /* [B, in], row stride x_ld */
+    mv3d_fc_chain_layer l[MV3D_FC_CHAIN_MAX];
+} mv3d_fc_chain;
+int mv3d_fc_chain_fwd(const mv3d_fc_chain* chain, void* stream);
 size_t mv3d_fc_workspace_bytes(int B, int in, int out);
 
 /* ---- element-wise pieces -------------------------------------------------------------------- */

@@ -313,6 +313,53 @@ def test_round1_kernels_at_batch_64():
         L().set_diagnostics(old)
 
 
+def test_small_fc_chain_and_fused_backward_equal_per_layer_calls():
+    """The angle MLP (appearance_flow_model.py:101-103: 2 -> 64 -> 64 -> 64, the last output a slice of the [fc1, a2] buffer) as ONE
+    forward launch (mv3d_fc_chain_fwd) and one backward launch per layer (mv3d_fc_wgrad_dgrad): bit-identical to the per-layer
+    calls they replace, and within the per-op bar of the oracle."""
+    B, widths, y_lds = 64, [2, 64, 64, 64], [64, 64, 96]
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((B, widths[0])).astype(np.float32)
+    Ms = [(rng.standard_normal((widths[k], widths[k + 1])) / np.sqrt(widths[k])).astype(np.float32) for k in range(3)]
+    bs = [rng.standard_normal(widths[k + 1]).astype(np.float32) for k in range(3)]
+    dx_, dMs, dbs = dev(x), [dev(m) for m in Ms], [dev(b) for b in bs]
+    ws = Ws(int(L().fc_workspace_bytes(B, 64, 64)))
+    # per-layer reference on the device
+    ys_ref, cur, cur_ld = [], dx_, widths[0]
+    for k in range(3):
+        y = torch.full((B, y_lds[k]), 7.0, device='cuda')
+        epi = _lib.epilogue(dbs[k].data_ptr(), _lib.ACT_LRELU, 0.2)
+        L().fc_fwd(B, widths[k], widths[k + 1], cur.data_ptr(), cur_ld, dMs[k].data_ptr(), y.data_ptr(), y_lds[k], C.byref(epi), ws.ptr, ws.bytes, stream())
+        ys_ref.append(y); cur, cur_ld = y, y_lds[k]
+    # the chain
+    ys = [torch.full((B, y_lds[k]), 7.0, device='cuda') for k in range(3)]
+    c = _lib.FcChain()
+    c.B, c.nlayers, c.in_, c.x_ld, c.x = B, 3, widths[0], widths[0], dx_.data_ptr()
+    for k in range(3):
+        c.l[k].M, c.l[k].bias, c.l[k].y, c.l[k].y_ld, c.l[k].out = dMs[k].data_ptr(), dbs[k].data_ptr(), ys[k].data_ptr(), y_lds[k], widths[k + 1]
+        c.l[k].act, c.l[k].leak = _lib.ACT_LRELU, 0.2
+    L().fc_chain_fwd(C.byref(c), stream())
+    h = x
+    for k in range(3):
+        assert np.array_equal(host(ys[k]), host(ys_ref[k]))
+        h = ops.absact_fwd(ops.linear_fwd(h, Ms[k], bs[k]), 'lrelu')
+        assert rel_err(host(ys[k])[:, :widths[k + 1]], h) < TOL
+    # backward of the middle layer: filter + data gradient in one launch vs the two calls
+    dy = rng.standard_normal((B, y_lds[1])).astype(np.float32)
+    ddy = dev(dy)
+    gm1, gb1, gx1 = (torch.full(sh, float('nan'), device='cuda') for sh in ((64, 64), (64,), (B, y_lds[0])))
+    gm2, gb2, gx2 = (torch.full(sh, float('nan'), device='cuda') for sh in ((64, 64), (64,), (B, y_lds[0])))
+    epi = _lib.epilogue(None, 0, 0.2, _lib.ACT_LRELU, 0.2, ys[0].data_ptr(), y_lds[0])
+    L().fc_wgrad(B, 64, 64, ys[0].data_ptr(), y_lds[0], ddy.data_ptr(), y_lds[1], gm1.data_ptr(), gb1.data_ptr(), ws.ptr, ws.bytes, stream())
+    L().fc_dgrad(B, 64, 64, ddy.data_ptr(), y_lds[1], dMs[1].data_ptr(), gx1.data_ptr(), y_lds[0], C.byref(epi), ws.ptr, ws.bytes, stream())
+    L().fc_wgrad_dgrad(B, 64, 64, ys[0].data_ptr(), y_lds[0], ddy.data_ptr(), y_lds[1], dMs[1].data_ptr(), gm2.data_ptr(), gb2.data_ptr(),
+                       gx2.data_ptr(), y_lds[0], C.byref(epi), ws.ptr, ws.bytes, stream())
+    assert np.array_equal(host(gm1), host(gm2)) and np.array_equal(host(gb1), host(gb2)) and np.array_equal(host(gx1), host(gx2))
+    rdx, rdm, rdb = ops.linear_bwd(host(ys[0])[:, :64], Ms[1], dy[:, :64])
+    assert rel_err(host(gm2), rdm) < TOL and rel_err(host(gb2), rdb) < TOL
+    assert rel_err(host(gx2)[:, :64], rdx * _slopes(host(ys[0])[:, :64])) < TOL
+
+
 def test_split_k_small_image_rung_at_batch_64():
     """diagnostics 16777216: the 8 x 8 / 4 x 4 layers on the kernels sconv replaced (chunks split over workgroups + split-K
     epilogue launch) stay a fallback rung and stay correct at the benchmarked shapes"""

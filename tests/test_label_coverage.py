@@ -29,6 +29,8 @@ ELEMENTWISE = {
     'adam': 'tests/test_gpu_ops.py::test_adam_bit_exact_vs_oracle',
     'grad_finalize_adam': 'tests/test_gpu_layers.py::test_fused_step_equals_unfused_step',     # == reduce_slabs per layer + adam, bit for bit
     'adam_advance': 'tests/test_gpu_layers.py::test_fused_fc_wgrad_adam_equals_wgrad_then_adam',
+    'small_fc_chain_fwd': 'tests/test_gpu_layers.py::test_small_fc_chain_and_fused_backward_equal_per_layer_calls',
+    'small_fc_bwd': 'tests/test_gpu_layers.py::test_small_fc_chain_and_fused_backward_equal_per_layer_calls',
 }
 
 
