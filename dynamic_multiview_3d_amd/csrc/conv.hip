@@ -1093,32 +1093,44 @@ __global__ __launch_bounds__(256) void small_fc_wgrad_kernel(int B, int in, int 
         db[o] = acc;
     }
 }
-// wgrad and dgrad of one small layer in one launch: blocks [0, wblocks) are small_fc_wgrad_kernel's, the rest small_fc_dgrad_kernel's
+// wgrad and dgrad of one small layer in one launch: blocks [0, wblocks) do small_fc_wgrad_kernel's elements, the rest
+// small_fc_dgrad_kernel's -- same products, same order -- but with both operands of a block staged in LDS by ONE round of loads
+// (B, in, out <= 64..128: <= 64 KiB): the per-layer kernels read them from L2 inside the loop, eight rounds of latency per element.
 __global__ __launch_bounds__(256) void small_fc_bwd_kernel(int B, int in, int out, const float* x, int x_ld, const float* dy, int dy_ld,
                                                           const float* M, float* dM, float* db, float* dx, int dx_ld, const IgemmParams ep,
                                                           int wblocks) {
+    extern __shared__ __attribute__((aligned(16))) float sb[];
+    const int tid = threadIdx.x;
+    float* s_dy = sb;                                   // [B][out]
+    for (int idx = tid; idx < B * out; idx += 256) { const int b = idx / out, o = idx - b * out; s_dy[idx] = dy[(int64_t)b * dy_ld + o]; }
     if ((int)blockIdx.x < wblocks) {
-        const int idx = blockIdx.x * 256 + threadIdx.x;
+        float* s_x = sb + B * out;                      // [B][in]
+        for (int idx = tid; idx < B * in; idx += 256) { const int b = idx / in, i = idx - b * in; s_x[idx] = x[(int64_t)b * x_ld + i]; }
+        __syncthreads();
+        const int idx = blockIdx.x * 256 + tid;
         if (idx >= (in + 1) * out) return;
         const int i = idx / out, o = idx - i * out;
         float acc = 0.f;
         if (i < in) {
 #pragma unroll 8
-            for (int b = 0; b < B; ++b) acc = fmaf(x[(int64_t)b * x_ld + i], dy[(int64_t)b * dy_ld + o], acc);
+            for (int b = 0; b < B; ++b) acc = fmaf(s_x[b * in + i], s_dy[b * out + o], acc);
             dM[(int64_t)i * out + o] = acc;
         } else if (db) {
 #pragma unroll 8
-            for (int b = 0; b < B; ++b) acc += dy[(int64_t)b * dy_ld + o];
+            for (int b = 0; b < B; ++b) acc += s_dy[b * out + o];
             db[o] = acc;
         }
         return;
     }
-    const int idx = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+    float* s_m = sb + B * out;                          // [in][out + 1]
+    for (int idx = tid; idx < in * out; idx += 256) { const int i = idx / out, o = idx - i * out; s_m[i * (out + 1) + o] = M[idx]; }
+    __syncthreads();
+    const int idx = ((int)blockIdx.x - wblocks) * 256 + tid;
     if (idx >= B * in) return;
     const int b = idx / in, i = idx - b * in;
     float acc = 0.f;
 #pragma unroll 8
-    for (int o = 0; o < out; ++o) acc = fmaf(dy[(int64_t)b * dy_ld + o], M[(int64_t)i * out + o], acc);
+    for (int o = 0; o < out; ++o) acc = fmaf(s_dy[b * out + o], s_m[i * (out + 1) + o], acc);
     dx[(int64_t)b * dx_ld + i] = epilogue_value(ep, acc, b, i);
 }
 
@@ -1801,8 +1813,14 @@ int mv3d_fc_wgrad_dgrad(int B, int in, int out, const void* x, int x_ld, const v
         if (rc != MV3D_OK) return rc;
         IgemmParams ep = {}; fill_epilogue(ep, dx_epi);
         const int wblocks = cdiv((in + 1) * out, 256), dblocks = cdiv(B * in, 256);
+        const size_t lds = ((size_t)B * out + std::max((size_t)B * in, (size_t)in * (out + 1))) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&small_fc_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipGetLastError();        // recording without a device: the attribute call fails and nothing is launched
+        }
+        if (lds <= 64 * 1024)
         return dispatch(stream, OpInfo{"small_fc_bwd", 4.0 * B * in * out, 4.0 * (2.0 * B * in + 2.0 * in * out + 2.0 * B * out)}, [=](hipStream_t s) {
-            small_fc_bwd_kernel<<<wblocks + dblocks, 256, 0, s>>>(B, in, out, (const float*)x, x_ld, (const float*)dy, dy_ld, (const float*)M,
+            small_fc_bwd_kernel<<<wblocks + dblocks, 256, lds, s>>>(B, in, out, (const float*)x, x_ld, (const float*)dy, dy_ld, (const float*)M,
                                                                   (float*)dM, (float*)db, (float*)dx, dx_ld, ep, wblocks);
             return launched("small_fc_bwd_kernel");
         });
@@ -1832,8 +1850,9 @@ int mv3d_fc_chain_fwd(const mv3d_fc_chain* c, void* stream) {
     size_t welems = 0;
     { int k = c->in; for (int l = 0; l < c->nlayers; ++l) { welems += (size_t)k * c->l[l].out; k = c->l[l].out; } }
     const size_t lds = (((welems + 3) & ~(size_t)3) + 2 * 256) * sizeof(float);       // <= 66 KiB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_chain_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipGetLastError();
     return dispatch(stream, OpInfo{"small_fc_chain_fwd", flops, bytes}, [=](hipStream_t s) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_chain_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         fc_chain_fwd_kernel<<<blocks, 256, lds, s>>>(d);
         return launched("fc_chain_fwd_kernel");
     });
