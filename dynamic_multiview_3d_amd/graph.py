@@ -699,7 +699,9 @@ class Graph:
         for n in self.nodes:
             if isinstance(n, LinearNode):
                 n.chain = None
-        if os.environ.get('MV3D_FC_CHAINS', '1') == '0' or (os.environ.get('MV3D_DISABLE') and int(os.environ['MV3D_DISABLE']) & 4):
+        cur = self.lib.set_diagnostics(0)          # the live mask (mv3d_set_diagnostics returns the previous one)
+        self.lib.set_diagnostics(cur)
+        if os.environ.get('MV3D_FC_CHAINS', '1') == '0' or (cur & 4):       # bit 4: no small-fc kernels
             return
         def tensors_of(node):
             for val in vars(node).values():
