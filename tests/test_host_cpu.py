@@ -36,6 +36,31 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.ConvGeom) == 14 * 4
     assert _lib.Epilogue.bias.offset == 0 and _lib.Epilogue.act.offset == 8
     assert _lib.Epilogue.gmask_ref.offset == 24 and C.sizeof(_lib.Epilogue) == 40
+    # mv3d_fc_chain_layer: three pointers + four 32-bit fields; mv3d_fc_chain: four 32-bit fields, a pointer, four layers
+    assert C.sizeof(_lib.FcChainLayer) == 40 and _lib.FcChainLayer.y_ld.offset == 24 and _lib.FcChainLayer.leak.offset == 36
+    assert _lib.FcChain.x.offset == 16 and _lib.FcChain.l.offset == 24 and C.sizeof(_lib.FcChain) == 24 + 4 * 40
+
+
+def test_small_fc_chains_are_found_and_can_be_switched_off(lib, monkeypatch):
+    """The angle MLP a0 -> a1 -> a2 (appearance_flow_model.py:101-103) is one forward launch, recorded at the position of a2 (the
+    launch that writes into the [fc1, a2] buffer: the fc hazard of the pipelined optimiser points at or in front of it); its data
+    gradients ride the filter-gradient stream with the filter gradients (one launch per layer); MV3D_FC_CHAINS=0 keeps one
+    launch per layer."""
+    from dynamic_multiview_3d_amd.appearance_flow_model import AppearanceFlowModel
+    m = AppearanceFlowModel({'batch_size': 8, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cpu')
+    g = m.graph
+    fwd = [o[0] for o in _lib.plan_ops(g.plan_fwd)]
+    assert fwd.count('small_fc_chain_fwd') == 1 and 'small_fc_fwd' not in fwd
+    chain = [n for n in g.nodes if getattr(n, 'chain', None)]
+    assert [n.m.name.split('/')[0] for n in chain] == ['a0', 'a1', 'a2'] and chain[0].chain[-1] is chain[2]
+    assert g._fwd_wait_idx is not None and g._fwd_wait_idx <= fwd.index('small_fc_chain_fwd')
+    bwd = [o[0] for o in _lib.plan_ops(g.plan_bwd_fused)]
+    assert bwd.count('small_fc_bwd') == 2 and bwd.count('small_fc_wgrad') == 1 and 'small_fc_dgrad' not in bwd
+    monkeypatch.setenv('MV3D_FC_CHAINS', '0')
+    m2 = AppearanceFlowModel({'batch_size': 8, 'learning_rate': 1e-4}, load_tfrec=False, build_loss=True, device='cpu')
+    fwd2 = [o[0] for o in _lib.plan_ops(m2.graph.plan_fwd)]
+    assert fwd2.count('small_fc_fwd') == 3 and 'small_fc_chain_fwd' not in fwd2
+    assert len(fwd2) == len(fwd) + 2
 
 
 def test_validation_without_device(lib):
